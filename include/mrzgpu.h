@@ -1,0 +1,170 @@
+/*
+ * mrzgpu.h -- C ABI of libmrzgpu.so: the MI355X (gfx950) implementation of the
+ * modern-rzip "rzip stage" hot path.  Plain C, plain pointers and sizes; no
+ * torch / C++ types cross this boundary.  Every entry point names the
+ * reference interface (file:line in the reference tree) it replaces.
+ *
+ * Error model: every function returns 0 on success or a negative MRZ_E_* code
+ * (the library never calls exit(); the reference's fatal() policy,
+ * include/util.h:50-62, stays with the host program).  mrz_strerror() gives
+ * text.  There is NO CPU fallback: without a usable HIP device mrz_open()
+ * fails with MRZ_E_NODEVICE.
+ *
+ * Threading: one mrz_ctx per host thread / HIP stream.  A ctx owns its device
+ * buffers (hash table, tag/bitmap scratch, event list, output streams) and one
+ * HIP stream; calls on different ctxs may run concurrently.
+ */
+#ifndef MRZGPU_H
+#define MRZGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRZ_ABI_VERSION 1
+
+enum {
+    MRZ_OK = 0,
+    MRZ_E_ARG = -1,      /* bad argument */
+    MRZ_E_NODEVICE = -2, /* no HIP device / HIP runtime failure at open */
+    MRZ_E_NOMEM = -3,    /* device or host allocation failed */
+    MRZ_E_HIP = -4,      /* HIP runtime error during a call (see mrz_last_hip_error) */
+    MRZ_E_OVERFLOW = -5, /* internal capacity exceeded (should not happen) */
+    MRZ_E_STATE = -6     /* call order violated (e.g. fetch before a chunk ran) */
+};
+
+/* where a caller-supplied buffer lives */
+enum { MRZ_MEM_HOST = 0, MRZ_MEM_DEVICE = 1 };
+
+typedef struct mrz_ctx mrz_ctx;
+
+/* The seven counters of struct rzip_state.stats
+ * (include/mrzip_private.h:407-415, printed at src/rzip.c:1108-1115). */
+typedef struct {
+    int64_t inserts;
+    int64_t literals;
+    int64_t literal_bytes;
+    int64_t matches;
+    int64_t match_bytes;
+    int64_t tag_hits;
+    int64_t tag_misses;
+} mrz_stats;
+
+/* Result of one chunk (what hash_search leaves in the two streams). */
+typedef struct {
+    int64_t s0_len;      /* control stream bytes incl. 00 00 00 terminator + 4 CRC bytes */
+    int64_t s1_len;      /* literal stream bytes */
+    uint32_t crc32;      /* CRC-32 of the chunk (src/rzip.c:662) */
+    uint32_t reserved;
+    const uint8_t *d_s0; /* DEVICE pointers, valid until the next chunk / mrz_close */
+    const uint8_t *d_s1;
+    mrz_stats stats;     /* counters of THIS chunk (the reference accumulates them per file) */
+    /* final matcher state, for state-parity tests and -vv style reporting */
+    int64_t min_mask;    /* rzip_state.minimum_tag_mask at chunk end */
+    int64_t hash_count;  /* rzip_state.hash_count at chunk end */
+    int64_t n_events;    /* emitted matches before 0xFFFF splitting */
+} mrz_chunk_result;
+
+/* per-kernel device times of the last chunk, milliseconds (HIP events on the
+ * ctx stream; filled only when profiling was enabled with mrz_set_profiling) */
+typedef struct {
+    float tagscan_ms;   /* sum over segments */
+    float sequencer_ms; /* sum over segments */
+    float encode_ms;
+    float crc_ms;
+    float total_ms;     /* first launch -> last kernel done */
+    int32_t n_segments;
+    int32_t reserved;
+} mrz_timings;
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Replaces the per-file set-up half of rzip_fd (src/rzip.c:836-913): level ->
+ * levels[] row (:65-73,896), hash_index (:669-673,901), hash table allocation
+ * (:521-530).  max_chunk sizes the device scratch; a larger chunk later makes
+ * the ctx grow.  device = HIP ordinal. */
+int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk);
+void mrz_close(mrz_ctx *ctx);
+
+int mrz_abi_version(void);
+const char *mrz_strerror(int code);
+/* last hipError_t seen by this ctx (0 = hipSuccess) and its text */
+int mrz_last_hip_error(const mrz_ctx *ctx, const char **text);
+
+/* The HIP stream the ctx launches on, as an opaque handle (hipStream_t), so a
+ * host framework can order its own work or record events against it. */
+void *mrz_stream(const mrz_ctx *ctx);
+int mrz_synchronize(mrz_ctx *ctx);
+int mrz_set_profiling(mrz_ctx *ctx, int enable);
+int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out);
+
+/* ---- the rzip stage ---------------------------------------------------- */
+
+/* Replaces rzip_chunk -> hash_search (src/rzip.c:763-792,507-667) for one
+ * chunk: tag scan (:330-358), table look-up / insert / cull (:232-328,426-462),
+ * lazy match selection and emission (:548-599), record encoding
+ * (:163-227), per-chunk CRC-32 (:488-505,601-666).
+ *   chunk, n        the chunk bytes (host or device memory per `where`)
+ *   chunk_bytes     width of match distances (src/rzip.c:1006-1008); use
+ *                   mrz_chunk_bytes(n)
+ *   victim_round    in/out: the process-lifetime `static victim_round`
+ *                   (src/rzip.c:259); pass 0 for the first chunk of a process
+ *                   and chain the returned value into the next chunk.
+ * The two output streams stay on the device (res->d_s0 / d_s1); copy them out
+ * with mrz_fetch_streams.  Returns after all device work has completed. */
+int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int where, int chunk_bytes, int64_t *victim_round,
+                   mrz_chunk_result *res);
+
+/* Copies the last chunk's streams to host memory (either may be NULL). */
+int mrz_fetch_streams(mrz_ctx *ctx, uint8_t *s0_host, uint8_t *s1_host);
+
+/* src/rzip.c:1006-1008 */
+int mrz_chunk_bytes(int64_t chunk_size);
+
+/* Debug / parity: copy the hash table (nslots * 16 bytes, struct hash_entry
+ * layout {i64 offset; i64 tag}, src/rzip.c:59-62) of the last chunk to host. */
+int64_t mrz_table_slots(const mrz_ctx *ctx);
+int mrz_fetch_table(mrz_ctx *ctx, void *host_dst);
+
+/* ---- CRC-32 alone (libgcrypt GCRY_MD_CRC32 as used at src/rzip.c:494,648) -- */
+int mrz_crc32(mrz_ctx *ctx, const void *buf, int64_t n, int where, uint32_t *crc_out);
+
+/* ---- LZ4 compressibility gate ------------------------------------------ */
+
+/* Replaces `static int lz4_compresses(rzip_control*, uchar *s_buf, i64 s_len)`
+ * (src/stream.c:116,1685-1733) for a BATCH of stream blocks: result[i] is
+ * exactly what the reference returns for block i (0 = incompressible, else
+ * 1..100 = percent), with control->threshold = `threshold`.
+ * bufs[i]/lens[i]: the blocks (all host or all device per `where`). */
+int mrz_lz4_compresses_batch(mrz_ctx *ctx, const void *const *bufs, const int64_t *lens, int count, int where,
+                             int threshold, int *results);
+/* single-block convenience with the reference's exact shape */
+int mrz_lz4_compresses(mrz_ctx *ctx, const void *s_buf, int64_t s_len, int where, int threshold, int *result);
+/* the size LZ4_compress_default(src, dst, n, n + 1) returns (0 = does not fit),
+ * src/stream.c:1705 -- exposed for parity tests */
+int mrz_lz4_sizes(mrz_ctx *ctx, const void *const *bufs, const int *lens, int count, int where, int *sizes);
+
+/* ---- BLAKE2b (co-resident checksum kernel) ------------------------------ */
+
+/* Streaming triple mirroring common/blake2b.h:47-49
+ * (blake2b_init / blake2b_update / blake2b_final); the state lives on the
+ * device and the kernel runs on a second low-priority stream of the ctx so it
+ * overlaps the rzip kernels. */
+typedef struct mrz_blake2b mrz_blake2b;
+int mrz_blake2b_init(mrz_ctx *ctx, mrz_blake2b **st, size_t outlen);
+int mrz_blake2b_update(mrz_blake2b *st, const void *in, size_t inlen, int where);
+int mrz_blake2b_final(mrz_blake2b *st, void *out_host, size_t outlen); /* frees st */
+
+/* Many independent messages at once (ar-mrzip hashes every file separately,
+ * ar-mrzip/ar-mrzip.cpp:139-171): digest i (outlen bytes) is written to
+ * out_host + i*outlen. */
+int mrz_blake2b_batch(mrz_ctx *ctx, const void *const *msgs, const int64_t *lens, int count, int where, size_t outlen,
+                      uint8_t *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

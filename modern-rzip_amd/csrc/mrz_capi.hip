@@ -1,0 +1,481 @@
+// mrz_capi.hip -- the C-ABI layer of libmrzgpu.so (include/mrzgpu.h): context
+// and device-buffer management, chunk orchestration (HIP stream of launches),
+// nothing else.  Host code only; the kernels live in the other .hip files.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/mrzgpu.h"
+#include "mrz_kernels.h"
+
+// positions per segment: tags 8 B/position -> 128 MiB scratch, bitmap 2 MiB
+#define MRZ_SEG_POSITIONS (16ll << 20)
+
+struct mrz_ctx {
+    int device;
+    int level;
+    unsigned mb_used, initial_freq, max_chain;
+    int hash_bits;
+    int64_t nslots;
+    hipStream_t stream;
+    hipError_t last_err;
+    int profiling;
+    mrz_timings timings;
+
+    int64_t h_index[256];
+    int64_t *d_index;
+    mrz_slot *d_tab;
+    mrz_seq_state *d_state;
+    int64_t *d_tags;
+    uint16_t *d_bitmap;
+    mrz_event *d_events;
+    int64_t event_cap;
+    int64_t *d_block_s0, *d_block_s1;
+    int64_t block_cap, block1_cap;
+    int64_t *d_lit_off;
+    int64_t lit_off_cap;
+    mrz_enc_totals *d_totals;
+    uint8_t *d_s0, *d_s1;
+    int64_t s0_cap, s1_cap;
+    int64_t s0_len, s1_len;
+    uint8_t *d_in;  // staging for host-resident chunks
+    int64_t in_cap;
+    mrz_crc_tables *d_crc_tables;
+    uint32_t *d_crc_parts;
+    int64_t crc_parts_cap;
+    uint32_t *d_crc_out;
+    int have_chunk;
+
+    // LZ4 / BLAKE2b scratch lives in their own translation units
+    void *lz4_scratch;
+    void *b2_scratch;
+};
+
+// levels[] rows {mb_used, initial_freq, max_chain_len}, src/rzip.c:65-73
+static const unsigned k_levels[10][3] = { { 1, 4, 1 },  { 2, 4, 2 },  { 4, 4, 2 },   { 8, 4, 2 },   { 16, 4, 3 },
+                                          { 32, 4, 4 }, { 32, 2, 6 }, { 64, 1, 16 }, { 64, 1, 32 }, { 64, 1, 128 } };
+
+// init_hash_indexes (src/rzip.c:669-673): (random() << 16) ^ random() from
+// glibc's TYPE_3 additive-feedback generator at its default seed 1, computed
+// here so the table does not depend on what else the host process did with
+// random().
+static void mrz_make_hash_index(int64_t H[256]) {
+    int32_t r[31];
+    int32_t word = 1;
+    r[0] = 1;
+    for (int i = 1; i < 31; i++) {
+        const long hi = word / 127773, lo = word % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        r[i] = word = (int32_t)w;
+    }
+    int f = 3, b = 0;
+    uint32_t draw[512];
+    for (int k = -310; k < 512; k++) {
+        const uint32_t s = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)s;
+        if (++f == 31) f = 0;
+        if (++b == 31) b = 0;
+        if (k >= 0) draw[k] = s >> 1;
+    }
+    for (int i = 0; i < 256; i++) H[i] = ((int64_t)draw[2 * i] << 16) ^ (int64_t)draw[2 * i + 1];
+}
+
+#define HIPCHK(ctx, expr)                     \
+    do {                                      \
+        hipError_t e__ = (expr);              \
+        if (e__ != hipSuccess) {              \
+            (ctx)->last_err = e__;            \
+            return MRZ_E_HIP;                 \
+        }                                     \
+    } while (0)
+
+template <typename T>
+static int mrz_grow(mrz_ctx *ctx, T **ptr, int64_t *cap, int64_t want) {
+    if (want <= *cap && *ptr) return MRZ_OK;
+    if (*ptr) {
+        hipFree(*ptr);
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    int64_t ask = want < 16 ? 16 : want;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)ask * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->last_err = e;
+        return MRZ_E_NOMEM;
+    }
+    *ptr = (T *)p;
+    *cap = ask;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_abi_version(void) { return MRZ_ABI_VERSION; }
+
+extern "C" const char *mrz_strerror(int code) {
+    switch (code) {
+        case MRZ_OK: return "ok";
+        case MRZ_E_ARG: return "bad argument";
+        case MRZ_E_NODEVICE: return "no usable HIP device (libmrzgpu has no CPU fallback)";
+        case MRZ_E_NOMEM: return "out of memory";
+        case MRZ_E_HIP: return "HIP runtime error";
+        case MRZ_E_OVERFLOW: return "internal capacity exceeded";
+        case MRZ_E_STATE: return "call order violated";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int mrz_last_hip_error(const mrz_ctx *ctx, const char **text) {
+    if (!ctx) return 0;
+    if (text) *text = hipGetErrorString(ctx->last_err);
+    return (int)ctx->last_err;
+}
+
+extern "C" int mrz_chunk_bytes(int64_t chunk_size) {
+    int bits = 8;
+    while (chunk_size >> bits > 0) bits++;
+    return bits / 8 + (bits % 8 ? 1 : 0);
+}
+
+extern "C" void mrz_close(mrz_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_index);
+    hipFree(ctx->d_tab);
+    hipFree(ctx->d_state);
+    hipFree(ctx->d_tags);
+    hipFree(ctx->d_bitmap);
+    hipFree(ctx->d_events);
+    hipFree(ctx->d_block_s0);
+    hipFree(ctx->d_block_s1);
+    hipFree(ctx->d_lit_off);
+    hipFree(ctx->d_totals);
+    hipFree(ctx->d_s0);
+    hipFree(ctx->d_s1);
+    hipFree(ctx->d_in);
+    hipFree(ctx->d_crc_tables);
+    hipFree(ctx->d_crc_parts);
+    hipFree(ctx->d_crc_out);
+    if (ctx->lz4_scratch) hipFree(ctx->lz4_scratch);
+    if (ctx->b2_scratch) hipFree(ctx->b2_scratch);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk) {
+    if (!out || level < 1 || level > 9 || max_chunk < 0) return MRZ_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MRZ_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MRZ_E_NODEVICE;
+    mrz_ctx *ctx = (mrz_ctx *)calloc(1, sizeof(mrz_ctx));
+    if (!ctx) return MRZ_E_NOMEM;
+    ctx->device = device;
+    ctx->level = level;
+    ctx->mb_used = k_levels[level][0];
+    ctx->initial_freq = k_levels[level][1];
+    ctx->max_chain = k_levels[level][2];
+    // table geometry, src/rzip.c:521-530
+    const int64_t want = (int64_t)ctx->mb_used * (1048576 / 16);
+    for (ctx->hash_bits = 0; (1ll << ctx->hash_bits) < want; ctx->hash_bits++) {
+    }
+    ctx->nslots = 1ll << ctx->hash_bits;
+    mrz_make_hash_index(ctx->h_index);
+
+    int rc = MRZ_OK;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) rc = MRZ_E_NODEVICE;
+    int64_t cap;
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_index, &cap, 256); }
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tab, &cap, ctx->nslots); }
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_state, &cap, 1); }
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tags, &cap, MRZ_SEG_POSITIONS); }
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_bitmap, &cap, MRZ_SEG_POSITIONS / 16 + 64); }
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_totals, &cap, 1); }
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_crc_out, &cap, 4); }
+    if (!rc) {
+        void *p = nullptr;
+        if (hipMalloc(&p, mrz_crc_tables_size()) != hipSuccess)
+            rc = MRZ_E_NOMEM;
+        else
+            ctx->d_crc_tables = (mrz_crc_tables *)p;
+    }
+    if (!rc) {
+        mrz_crc_tables *tb = (mrz_crc_tables *)malloc(mrz_crc_tables_size());
+        if (!tb)
+            rc = MRZ_E_NOMEM;
+        else {
+            mrz_crc_build_tables(tb);
+            if (hipMemcpy(ctx->d_crc_tables, tb, mrz_crc_tables_size(), hipMemcpyHostToDevice) != hipSuccess)
+                rc = MRZ_E_HIP;
+            free(tb);
+        }
+    }
+    if (!rc && hipMemcpy(ctx->d_index, ctx->h_index, sizeof(ctx->h_index), hipMemcpyHostToDevice) != hipSuccess)
+        rc = MRZ_E_HIP;
+    if (!rc && max_chunk > 0) {
+        rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, max_chunk / MRZ_MIN_MATCH + 2);
+        if (!rc) rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(max_chunk));
+    }
+    if (rc) {
+        mrz_close(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MRZ_OK;
+}
+
+extern "C" void *mrz_stream(const mrz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int mrz_synchronize(mrz_ctx *ctx) {
+    if (!ctx) return MRZ_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MRZ_OK;
+}
+
+extern "C" int mrz_set_profiling(mrz_ctx *ctx, int enable) {
+    if (!ctx) return MRZ_E_ARG;
+    ctx->profiling = enable ? 1 : 0;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out) {
+    if (!ctx || !out) return MRZ_E_ARG;
+    *out = ctx->timings;
+    return MRZ_OK;
+}
+
+extern "C" int64_t mrz_table_slots(const mrz_ctx *ctx) { return ctx ? ctx->nslots : 0; }
+
+extern "C" int mrz_fetch_table(mrz_ctx *ctx, void *host_dst) {
+    if (!ctx || !host_dst) return MRZ_E_ARG;
+    if (!ctx->have_chunk) return MRZ_E_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(host_dst, ctx->d_tab, (size_t)ctx->nslots * sizeof(mrz_slot), hipMemcpyDeviceToHost));
+    return MRZ_OK;
+}
+
+// resolves a caller buffer to a device pointer (staging host memory)
+static int mrz_stage_input(mrz_ctx *ctx, const void *buf, int64_t n, int where, const uint8_t **dev) {
+    if (where == MRZ_MEM_DEVICE) {
+        *dev = (const uint8_t *)buf;
+        return MRZ_OK;
+    }
+    if (where != MRZ_MEM_HOST) return MRZ_E_ARG;
+    int rc = mrz_grow(ctx, &ctx->d_in, &ctx->in_cap, n + 64);
+    if (rc) return rc;
+    if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->d_in, buf, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    *dev = ctx->d_in;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_crc32(mrz_ctx *ctx, const void *buf, int64_t n, int where, uint32_t *crc_out) {
+    if (!ctx || !crc_out || n < 0 || (n > 0 && !buf)) return MRZ_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint8_t *d = nullptr;
+    int rc = mrz_stage_input(ctx, buf, n, where, &d);
+    if (rc) return rc;
+    rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(n));
+    if (rc) return rc;
+    HIPCHK(ctx, mrz_launch_crc32(ctx->stream, d, n, ctx->d_crc_tables, ctx->d_crc_parts, ctx->d_crc_out));
+    HIPCHK(ctx, hipMemcpyAsync(crc_out, ctx->d_crc_out, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MRZ_OK;
+}
+
+struct mrz_evpair {
+    hipEvent_t a, b;
+    int kind;  // 0 tagscan, 1 sequencer, 2 encode, 3 crc
+};
+
+extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int where, int chunk_bytes,
+                              int64_t *victim_round, mrz_chunk_result *res) {
+    if (!ctx || !res || !victim_round || n < 0 || (n > 0 && !chunk) || chunk_bytes < 1 || chunk_bytes > 8)
+        return MRZ_E_ARG;
+    if (*victim_round < 0 || *victim_round >= (int64_t)ctx->max_chain) return MRZ_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(res, 0, sizeof(*res));
+    memset(&ctx->timings, 0, sizeof(ctx->timings));
+    ctx->have_chunk = 0;
+    hipStream_t s = ctx->stream;
+
+    const uint8_t *d_buf = nullptr;
+    int rc = mrz_stage_input(ctx, chunk, n, where, &d_buf);
+    if (rc) return rc;
+    rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, n / MRZ_MIN_MATCH + 2);
+    if (rc) return rc;
+    rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(n));
+    if (rc) return rc;
+
+    // profiling events (optional)
+    mrz_evpair *evs = nullptr;
+    int nev = 0, evcap = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    const int64_t end = n - MRZ_MIN_MATCH;
+    const int64_t nseg = end > 0 ? (end + 1 + MRZ_SEG_POSITIONS - 1) / MRZ_SEG_POSITIONS : 0;
+    if (ctx->profiling) {
+        evcap = (int)(2 * nseg + 4);
+        evs = (mrz_evpair *)calloc((size_t)evcap, sizeof(mrz_evpair));
+        if (!evs) return MRZ_E_NOMEM;
+        hipEventCreate(&ev_begin);
+        hipEventCreate(&ev_end);
+        hipEventRecord(ev_begin, s);
+    }
+#define PROF_BEGIN(k)                                  \
+    do {                                               \
+        if (ctx->profiling && nev < evcap) {           \
+            evs[nev].kind = (k);                       \
+            hipEventCreate(&evs[nev].a);               \
+            hipEventCreate(&evs[nev].b);               \
+            hipEventRecord(evs[nev].a, s);             \
+        }                                              \
+    } while (0)
+#define PROF_END()                                     \
+    do {                                               \
+        if (ctx->profiling && nev < evcap) {           \
+            hipEventRecord(evs[nev].b, s);             \
+            nev++;                                     \
+        }                                              \
+    } while (0)
+
+    // hash_search prologue (src/rzip.c:518-546): zero the table, reset state
+    mrz_seq_state hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.n = n;
+    hs.end = end;
+    hs.min_mask = hs.tag_mask = (1ll << ctx->initial_freq) - 1;
+    hs.limit = ctx->nslots / 3 * 2;
+    hs.victim_round = *victim_round;
+    hs.max_chain = ctx->max_chain;
+    hs.slot_mask = ctx->nslots - 1;
+    hs.event_cap = ctx->event_cap;
+    hs.finished = end > 0 ? 0 : 1;
+    hipError_t herr = hipSuccess;
+    int64_t E = 0;
+    uint32_t crc = 0;
+    mrz_enc_totals tot;
+    memset(&tot, 0, sizeof(tot));
+
+#define STEP(expr)                       \
+    do {                                 \
+        if (herr == hipSuccess) herr = (expr); \
+    } while (0)
+
+    STEP(hipMemsetAsync(ctx->d_tab, 0, (size_t)ctx->nslots * sizeof(mrz_slot), s));
+    STEP(hipMemcpyAsync(ctx->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
+    STEP(hipMemsetAsync(ctx->d_totals, 0, sizeof(mrz_enc_totals), s));
+
+    PROF_BEGIN(3);
+    STEP(mrz_launch_crc32(s, d_buf, n, ctx->d_crc_tables, ctx->d_crc_parts, ctx->d_crc_out));
+    PROF_END();
+
+    for (int64_t sg = 0; sg < nseg && herr == hipSuccess; sg++) {
+        const int64_t seg_start = sg * MRZ_SEG_POSITIONS;
+        int64_t seg_len = end + 1 - seg_start;
+        if (seg_len > MRZ_SEG_POSITIONS) seg_len = MRZ_SEG_POSITIONS;
+        PROF_BEGIN(0);
+        STEP(mrz_launch_tagscan(s, d_buf, n, seg_start, seg_len, ctx->d_index, ctx->d_state, ctx->d_tags,
+                                ctx->d_bitmap));
+        PROF_END();
+        PROF_BEGIN(1);
+        STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
+                                  ctx->d_state, seg_start, seg_len));
+        PROF_END();
+    }
+    STEP(hipMemcpyAsync(&hs, ctx->d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
+    STEP(hipMemcpyAsync(&crc, ctx->d_crc_out, 4, hipMemcpyDeviceToHost, s));
+    STEP(hipStreamSynchronize(s));
+    if (herr == hipSuccess) {
+        if (hs.error || !hs.finished) rc = MRZ_E_OVERFLOW;
+        E = hs.n_events;
+    }
+
+    // record encoding
+    if (herr == hipSuccess && !rc) {
+        const int64_t nblocks = (E + 1 + 255) / 256;
+        rc = mrz_grow(ctx, &ctx->d_block_s0, &ctx->block_cap, nblocks);
+        if (!rc) rc = mrz_grow(ctx, &ctx->d_block_s1, &ctx->block1_cap, nblocks);
+        if (!rc) rc = mrz_grow(ctx, &ctx->d_lit_off, &ctx->lit_off_cap, E + 2);
+    }
+    if (herr == hipSuccess && !rc) {
+        PROF_BEGIN(2);
+        STEP(mrz_launch_enc_size(s, ctx->d_events, E, n, chunk_bytes, ctx->d_block_s0, ctx->d_block_s1, ctx->d_totals));
+        STEP(hipMemcpyAsync(&tot, ctx->d_totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+        STEP(hipStreamSynchronize(s));
+        if (herr == hipSuccess) {
+            rc = mrz_grow(ctx, &ctx->d_s0, &ctx->s0_cap, tot.s0_len + 7 + 16);
+            if (!rc) rc = mrz_grow(ctx, &ctx->d_s1, &ctx->s1_cap, tot.s1_len + 16);
+        }
+        if (herr == hipSuccess && !rc) {
+            STEP(mrz_launch_enc_write(s, d_buf, ctx->d_events, E, n, chunk_bytes, ctx->d_block_s0, ctx->d_block_s1,
+                                      ctx->d_s0, ctx->d_s1, tot.s1_len, ctx->d_lit_off, ctx->d_totals, crc));
+            STEP(hipMemcpyAsync(&tot, ctx->d_totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+        }
+        PROF_END();
+        if (ctx->profiling) hipEventRecord(ev_end, s);
+        STEP(hipStreamSynchronize(s));
+    }
+
+    if (ctx->profiling) {
+        hipStreamSynchronize(s);
+        for (int i = 0; i < nev; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, evs[i].a, evs[i].b) == hipSuccess) {
+                if (evs[i].kind == 0) ctx->timings.tagscan_ms += ms;
+                if (evs[i].kind == 1) ctx->timings.sequencer_ms += ms;
+                if (evs[i].kind == 2) ctx->timings.encode_ms += ms;
+                if (evs[i].kind == 3) ctx->timings.crc_ms += ms;
+            }
+            hipEventDestroy(evs[i].a);
+            hipEventDestroy(evs[i].b);
+        }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) ctx->timings.total_ms = ms;
+        ctx->timings.n_segments = (int32_t)nseg;
+        hipEventDestroy(ev_begin);
+        hipEventDestroy(ev_end);
+        free(evs);
+    }
+#undef PROF_BEGIN
+#undef PROF_END
+#undef STEP
+    if (herr != hipSuccess) {
+        ctx->last_err = herr;
+        return MRZ_E_HIP;
+    }
+    if (rc) return rc;
+
+    *victim_round = hs.victim_round;
+    ctx->s0_len = tot.s0_len + 7;
+    ctx->s1_len = tot.s1_len;
+    ctx->have_chunk = 1;
+    res->s0_len = ctx->s0_len;
+    res->s1_len = ctx->s1_len;
+    res->crc32 = crc;
+    res->d_s0 = ctx->d_s0;
+    res->d_s1 = ctx->d_s1;
+    res->stats.inserts = hs.inserts;
+    res->stats.tag_hits = hs.tag_hits;
+    res->stats.tag_misses = hs.tag_misses;
+    res->stats.literals = tot.literals + 1;  // the zero-length terminator counts (src/rzip.c:219,664)
+    res->stats.literal_bytes = tot.literal_bytes;
+    res->stats.matches = tot.matches;
+    res->stats.match_bytes = tot.match_bytes;
+    res->min_mask = hs.min_mask;
+    res->hash_count = hs.count;
+    res->n_events = E;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_fetch_streams(mrz_ctx *ctx, uint8_t *s0_host, uint8_t *s1_host) {
+    if (!ctx) return MRZ_E_ARG;
+    if (!ctx->have_chunk) return MRZ_E_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (s0_host && ctx->s0_len > 0)
+        HIPCHK(ctx, hipMemcpyAsync(s0_host, ctx->d_s0, (size_t)ctx->s0_len, hipMemcpyDeviceToHost, ctx->stream));
+    if (s1_host && ctx->s1_len > 0)
+        HIPCHK(ctx, hipMemcpyAsync(s1_host, ctx->d_s1, (size_t)ctx->s1_len, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MRZ_OK;
+}

@@ -1,0 +1,68 @@
+// mrz_device.h -- small device helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrz_common.h"
+
+typedef unsigned long long mrz_u64;
+
+// 16-byte load from an arbitrarily aligned address (gfx950 global memory
+// handles unaligned dwordx4; the builtin memcpy keeps the compiler honest
+// about the alignment it may assume).
+__device__ __forceinline__ uint4 mrz_ld16(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+__device__ __forceinline__ uint2 mrz_ld8(const uint8_t *p) {
+    uint2 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t mrz_ld4(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// index of the first differing byte of two 16-byte pieces (16 = identical)
+__device__ __forceinline__ int mrz_first_diff16(uint4 a, uint4 b) {
+    uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+    if (d0) return (__ffs((int)d0) - 1) >> 3;
+    if (d1) return 4 + ((__ffs((int)d1) - 1) >> 3);
+    if (d2) return 8 + ((__ffs((int)d2) - 1) >> 3);
+    if (d3) return 12 + ((__ffs((int)d3) - 1) >> 3);
+    return 16;
+}
+
+// number of equal bytes counted from byte 15 downwards (16 = identical)
+__device__ __forceinline__ int mrz_top_equal16(uint4 a, uint4 b) {
+    uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+    if (d3) return __clz((int)d3) >> 3;
+    if (d2) return 4 + (__clz((int)d2) >> 3);
+    if (d1) return 8 + (__clz((int)d1) >> 3);
+    if (d0) return 12 + (__clz((int)d0) >> 3);
+    return 16;
+}
+
+// wave-uniform broadcast of a 64-bit value held by lane `src`
+__device__ __forceinline__ int64_t mrz_bcast64(int64_t v, int src) {
+    int lo = __shfl((int)(uint32_t)(uint64_t)v, src, MRZ_WAVE);
+    int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, MRZ_WAVE);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// mask with the low `k` bits set, k in [0, 64]
+__device__ __forceinline__ mrz_u64 mrz_low_mask(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+
+// 0-based position of the k-th (k >= 0) set bit of m; m must have > k bits set
+__device__ __forceinline__ int mrz_nth_set(mrz_u64 m, int k) {
+    for (int i = 0; i < k; i++) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+
+// trailing-ones rank used by lesser_bitness (src/rzip.c:248-252): ffsll(~t)
+__device__ __forceinline__ int mrz_ones_rank(int64_t t) { return __ffsll((long long)~t); }

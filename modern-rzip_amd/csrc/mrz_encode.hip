@@ -1,0 +1,256 @@
+// mrz_encode.hip -- parallel back-end of the rzip stage: turns the sequencer's
+// event list into the two output streams.
+//
+// Restates put_match / put_literal / put_header / put_vchars / write_sbstream
+// (src/rzip.c:163-227) and the tail of hash_search (:619,:664-665):
+//   stream 0: literal run -> {00, len:u16le} per <=0xFFFF piece,
+//             match       -> {01, len:u16le, dist:u{chunk_bytes}le} per <=0xFFFF piece
+//             (dist = p - offset is the same for every piece of one match),
+//             end         -> 00 00 00 + CRC-32 (most significant byte first)
+//   stream 1: the literal bytes, concatenated.
+// Item i (0 <= i < E) is "the literal run before match i, then match i"; item E
+// is the trailing literal run.  Sizes are prefix-summed (two-level block scan),
+// then every item writes its records at its own offset and the literal bytes
+// are gathered by a grid-wide copy (16 B per thread, unaligned source).
+//
+// Bound: HBM (reads <= N literal bytes once, writes them once).
+#include "mrz_device.h"
+
+#define MRZ_ENC_THREADS 256
+
+__device__ __forceinline__ void mrz_item(const mrz_event *ev, int64_t E, int64_t n, int64_t i, int64_t *lit_from,
+                                         int64_t *lit_len, int64_t *mp, int64_t *mofs, int64_t *mlen) {
+    const int64_t prev_end = i ? ev[i - 1].p + ev[i - 1].len : 0;
+    *lit_from = prev_end;
+    if (i < E) {
+        *lit_len = ev[i].p - prev_end;
+        *mp = ev[i].p;
+        *mofs = ev[i].ofs;
+        *mlen = ev[i].len;
+    } else {
+        *lit_len = n - prev_end;
+        *mp = *mofs = *mlen = 0;
+    }
+}
+
+__device__ __forceinline__ int64_t mrz_pieces(int64_t len) { return (len + 0xFFFE) / 0xFFFF; }
+
+// block-wide exclusive scan of two int64 values; returns block totals
+__device__ static void mrz_block_scan2(int64_t &a, int64_t &b, int64_t &ta, int64_t &tb) {
+    __shared__ int64_t sa[MRZ_ENC_THREADS], sb[MRZ_ENC_THREADS];
+    const int tid = threadIdx.x;
+    sa[tid] = a;
+    sb[tid] = b;
+    __syncthreads();
+    for (int d = 1; d < MRZ_ENC_THREADS; d <<= 1) {
+        int64_t va = 0, vb = 0;
+        if (tid >= d) {
+            va = sa[tid - d];
+            vb = sb[tid - d];
+        }
+        __syncthreads();
+        sa[tid] += va;
+        sb[tid] += vb;
+        __syncthreads();
+    }
+    ta = sa[MRZ_ENC_THREADS - 1];
+    tb = sb[MRZ_ENC_THREADS - 1];
+    const int64_t ia = sa[tid] - a, ib = sb[tid] - b;
+    __syncthreads();
+    a = ia;
+    b = ib;
+}
+
+// pass 1: per-block totals of (stream-0 bytes, stream-1 bytes)
+__global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_size_kernel(const mrz_event *__restrict__ ev, int64_t E,
+                                                                       int64_t n, int cb,
+                                                                       int64_t *__restrict__ block_s0,
+                                                                       int64_t *__restrict__ block_s1) {
+    const int64_t i = (int64_t)blockIdx.x * MRZ_ENC_THREADS + threadIdx.x;
+    int64_t c0 = 0, c1 = 0;
+    if (i <= E) {
+        int64_t lf, ll, mp, mo, ml;
+        mrz_item(ev, E, n, i, &lf, &ll, &mp, &mo, &ml);
+        c0 = mrz_pieces(ll) * 3 + mrz_pieces(ml) * (3 + cb);
+        c1 = ll;
+    }
+    int64_t ta, tb;
+    mrz_block_scan2(c0, c1, ta, tb);
+    if (threadIdx.x == 0) {
+        block_s0[blockIdx.x] = ta;
+        block_s1[blockIdx.x] = tb;
+    }
+}
+
+// pass 2: one workgroup turns the block totals into exclusive offsets and
+// publishes the grand totals
+__global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_scan_kernel(int64_t *__restrict__ block_s0,
+                                                                       int64_t *__restrict__ block_s1,
+                                                                       int64_t nblocks,
+                                                                       mrz_enc_totals *__restrict__ totals) {
+    int64_t run0 = 0, run1 = 0;
+    for (int64_t base = 0; base < nblocks; base += MRZ_ENC_THREADS) {
+        const int64_t i = base + threadIdx.x;
+        int64_t a = i < nblocks ? block_s0[i] : 0, b = i < nblocks ? block_s1[i] : 0;
+        int64_t ta, tb;
+        mrz_block_scan2(a, b, ta, tb);
+        if (i < nblocks) {
+            block_s0[i] = run0 + a;
+            block_s1[i] = run1 + b;
+        }
+        run0 += ta;
+        run1 += tb;
+    }
+    if (threadIdx.x == 0) {
+        totals->s0_len = run0;
+        totals->s1_len = run1;
+    }
+}
+
+// pass 3: records into stream 0, per-item stream-1 offsets, statistics
+__global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_write_kernel(const mrz_event *__restrict__ ev, int64_t E,
+                                                                        int64_t n, int cb,
+                                                                        const int64_t *__restrict__ block_s0,
+                                                                        const int64_t *__restrict__ block_s1,
+                                                                        uint8_t *__restrict__ s0,
+                                                                        int64_t *__restrict__ lit_off,
+                                                                        mrz_enc_totals *__restrict__ totals,
+                                                                        uint32_t crc) {
+    const int64_t i = (int64_t)blockIdx.x * MRZ_ENC_THREADS + threadIdx.x;
+    int64_t c0 = 0, c1 = 0;
+    int64_t lf = 0, ll = 0, mp = 0, mo = 0, ml = 0;
+    if (i <= E) {
+        mrz_item(ev, E, n, i, &lf, &ll, &mp, &mo, &ml);
+        c0 = mrz_pieces(ll) * 3 + mrz_pieces(ml) * (3 + cb);
+        c1 = ll;
+    }
+    int64_t ta, tb;
+    mrz_block_scan2(c0, c1, ta, tb);
+    if (i > E) return;
+    int64_t o0 = block_s0[blockIdx.x] + c0;
+    const int64_t o1 = block_s1[blockIdx.x] + c1;
+    lit_off[i] = o1;
+    int64_t nlit = 0, nmat = 0;
+    for (int64_t rest = ll; rest > 0;) {
+        const int64_t piece = rest > 0xFFFF ? 0xFFFF : rest;
+        s0[o0] = 0;
+        s0[o0 + 1] = (uint8_t)piece;
+        s0[o0 + 2] = (uint8_t)(piece >> 8);
+        o0 += 3;
+        rest -= piece;
+        nlit++;
+    }
+    const int64_t dist = mp - mo;
+    for (int64_t rest = ml; rest > 0;) {
+        const int64_t piece = rest > 0xFFFF ? 0xFFFF : rest;
+        s0[o0] = 1;
+        s0[o0 + 1] = (uint8_t)piece;
+        s0[o0 + 2] = (uint8_t)(piece >> 8);
+        for (int k = 0; k < cb; k++) s0[o0 + 3 + k] = (uint8_t)((uint64_t)dist >> (8 * k));
+        o0 += 3 + cb;
+        rest -= piece;
+        nmat++;
+    }
+    // statistics (st->stats.* at src/rzip.c:188-189,219-220)
+    if (nlit) {
+        atomicAdd((unsigned long long *)&totals->literals, (unsigned long long)nlit);
+        atomicAdd((unsigned long long *)&totals->literal_bytes, (unsigned long long)ll);
+    }
+    if (nmat) {
+        atomicAdd((unsigned long long *)&totals->matches, (unsigned long long)nmat);
+        atomicAdd((unsigned long long *)&totals->match_bytes, (unsigned long long)ml);
+    }
+    if (i == E) {
+        // terminator literal + CRC (src/rzip.c:664-665); o0 == total s0_len here
+        lit_off[E + 1] = o1 + ll;
+        s0[o0] = 0;
+        s0[o0 + 1] = 0;
+        s0[o0 + 2] = 0;
+        s0[o0 + 3] = (uint8_t)(crc >> 24);
+        s0[o0 + 4] = (uint8_t)(crc >> 16);
+        s0[o0 + 5] = (uint8_t)(crc >> 8);
+        s0[o0 + 6] = (uint8_t)crc;
+    }
+}
+
+// pass 4: gather the literal bytes into stream 1 (write_sbstream, :197-211)
+__global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_literal_gather_kernel(const uint8_t *__restrict__ buf,
+                                                                             const mrz_event *__restrict__ ev,
+                                                                             int64_t E,
+                                                                             const int64_t *__restrict__ lit_off,
+                                                                             int64_t s1_len,
+                                                                             uint8_t *__restrict__ s1) {
+    __shared__ int64_t s_lo, s_hi;
+    const int64_t blk_o = (int64_t)blockIdx.x * MRZ_ENC_THREADS * 16;
+    // narrow the item range for this block: items lo..hi cover [blk_o, blk_o + 4096)
+    if (threadIdx.x < 2) {
+        int64_t target = threadIdx.x == 0 ? blk_o : blk_o + (int64_t)MRZ_ENC_THREADS * 16 - 1;
+        if (target >= s1_len) target = s1_len - 1;
+        int64_t lo = 0, hi = E;  // largest i with lit_off[i] <= target
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (lit_off[mid] <= target)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        if (threadIdx.x == 0)
+            s_lo = lo;
+        else
+            s_hi = lo;
+    }
+    __syncthreads();
+    const int64_t o = blk_o + (int64_t)threadIdx.x * 16;
+    if (o >= s1_len) return;
+    int64_t lo = s_lo, hi = s_hi;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (lit_off[mid] <= o)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    int64_t i = lo;
+    // skip empty runs so that lit_off[i] <= o < lit_off[i+1]
+    while (lit_off[i + 1] <= o) i++;
+    int64_t from = (i ? ev[i - 1].p + ev[i - 1].len : 0) + (o - lit_off[i]);
+    if (o + 16 <= lit_off[i + 1]) {
+        *reinterpret_cast<uint4 *>(s1 + o) = mrz_ld16(buf + from);
+        return;
+    }
+    const int64_t stop = (o + 16 < s1_len) ? o + 16 : s1_len;
+    int64_t run_end = lit_off[i + 1];
+    for (int64_t w = o; w < stop; w++) {
+        while (w >= run_end) {
+            i++;
+            run_end = lit_off[i + 1];
+            from = i ? ev[i - 1].p + ev[i - 1].len : 0;
+        }
+        s1[w] = buf[from++];
+    }
+}
+
+extern "C" hipError_t mrz_launch_enc_size(hipStream_t stream, const mrz_event *ev, int64_t E, int64_t n, int cb,
+                                          int64_t *block_s0, int64_t *block_s1, mrz_enc_totals *totals) {
+    const int64_t nblocks = (E + 1 + MRZ_ENC_THREADS - 1) / MRZ_ENC_THREADS;
+    hipLaunchKernelGGL(mrz_enc_size_kernel, dim3((unsigned)nblocks), dim3(MRZ_ENC_THREADS), 0, stream, ev, E, n, cb,
+                       block_s0, block_s1);
+    hipLaunchKernelGGL(mrz_enc_scan_kernel, dim3(1), dim3(MRZ_ENC_THREADS), 0, stream, block_s0, block_s1, nblocks,
+                       totals);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mrz_launch_enc_write(hipStream_t stream, const uint8_t *buf, const mrz_event *ev, int64_t E,
+                                           int64_t n, int cb, const int64_t *block_s0, const int64_t *block_s1,
+                                           uint8_t *s0, uint8_t *s1, int64_t s1_len, int64_t *lit_off,
+                                           mrz_enc_totals *totals, uint32_t crc) {
+    const int64_t nblocks = (E + 1 + MRZ_ENC_THREADS - 1) / MRZ_ENC_THREADS;
+    hipLaunchKernelGGL(mrz_enc_write_kernel, dim3((unsigned)nblocks), dim3(MRZ_ENC_THREADS), 0, stream, ev, E, n, cb,
+                       block_s0, block_s1, s0, lit_off, totals, crc);
+    if (s1_len > 0) {
+        const int64_t gblocks = (s1_len + MRZ_ENC_THREADS * 16 - 1) / (MRZ_ENC_THREADS * 16);
+        hipLaunchKernelGGL(mrz_literal_gather_kernel, dim3((unsigned)gblocks), dim3(MRZ_ENC_THREADS), 0, stream, buf,
+                           ev, E, lit_off, s1_len, s1);
+    }
+    return hipGetLastError();
+}

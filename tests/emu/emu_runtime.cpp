@@ -1,0 +1,173 @@
+// tests/emu/emu_runtime.cpp -- fiber scheduler of the wave64 SIMT emulator
+// (TEST INFRASTRUCTURE, see hip/hip_runtime.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include <vector>
+
+namespace emu {
+
+struct WaveSync {
+    int alive = 0, arrived = 0;
+    uint64_t phase = 0;
+    int64_t slot[2][64];
+    unsigned long long bal[2] = { 0, 0 };
+    void complete() {  // all live lanes have arrived: open the next phase
+        arrived = 0;
+        bal[(phase & 1) ^ 1] = 0;  // everyone has consumed the phase before this one
+        phase++;
+    }
+};
+struct BlockSync {
+    int alive = 0, arrived = 0;
+    uint64_t phase = 0;
+};
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    Idx tid;
+    int lane = 0;
+    WaveSync *wave = nullptr;
+    bool done = false;
+    const uint64_t *wait_ptr = nullptr;
+    uint64_t wait_val = 0;
+};
+
+Fiber *cur = nullptr;
+Idx cur_tid, cur_bid, cur_bdim, cur_gdim;
+static ucontext_t sched_ctx;
+static BlockSync blk;
+static const std::function<void()> *cur_body;
+static const size_t STACK = 256 * 1024;
+
+static void yield_wait(const uint64_t *ptr, uint64_t val) {
+    Fiber *me = cur;
+    me->wait_ptr = ptr;
+    me->wait_val = val;
+    swapcontext(&me->ctx, &sched_ctx);
+    // resumed: scheduler restored cur / cur_tid
+}
+
+static void wave_arrive(WaveSync *w) {
+    if (++w->arrived >= w->alive) {
+        w->complete();
+    } else {
+        const uint64_t ph = w->phase;
+        yield_wait(&w->phase, ph);
+    }
+}
+
+unsigned long long ballot(int pred) {
+    WaveSync *w = cur->wave;
+    const int par = (int)(w->phase & 1);
+    if (pred) w->bal[par] |= 1ull << cur->lane;
+    wave_arrive(w);
+    return w->bal[par];
+}
+
+int shfl(int v, int src) {
+    WaveSync *w = cur->wave;
+    const int par = (int)(w->phase & 1);
+    w->slot[par][cur->lane] = (int64_t)(uint32_t)v;
+    wave_arrive(w);
+    return (int)(uint32_t)w->slot[par][src & 63];
+}
+
+int shfl_xor(int v, int mask) {
+    WaveSync *w = cur->wave;
+    const int par = (int)(w->phase & 1);
+    w->slot[par][cur->lane] = (int64_t)(uint32_t)v;
+    const int src = (cur->lane ^ mask) & 63;
+    wave_arrive(w);
+    return (int)(uint32_t)w->slot[par][src];
+}
+
+void syncthreads() {
+    if (++blk.arrived >= blk.alive) {
+        blk.arrived = 0;
+        blk.phase++;
+    } else {
+        const uint64_t ph = blk.phase;
+        yield_wait(&blk.phase, ph);
+    }
+}
+
+static void fiber_main() {
+    (*cur_body)();
+    Fiber *me = cur;
+    me->done = true;
+    // a finished thread no longer takes part in rendezvous
+    WaveSync *w = me->wave;
+    w->alive--;
+    if (w->alive > 0 && w->arrived >= w->alive) w->complete();
+    blk.alive--;
+    if (blk.alive > 0 && blk.arrived >= blk.alive) {
+        blk.arrived = 0;
+        blk.phase++;
+    }
+    swapcontext(&me->ctx, &sched_ctx);
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    const unsigned nthreads = block.x * block.y * block.z;
+    const unsigned nwaves = (nthreads + 63) / 64;
+    static std::vector<Fiber> fibers;
+    static std::vector<WaveSync> waves;
+    if (fibers.size() < nthreads) {
+        size_t old = fibers.size();
+        fibers.resize(nthreads);
+        for (size_t i = old; i < nthreads; i++) fibers[i].stack = (char *)malloc(STACK);
+    }
+    if (waves.size() < nwaves) waves.resize(nwaves);
+    cur_body = &body;
+    cur_bdim = { block.x, block.y, block.z };
+    cur_gdim = { grid.x, grid.y, grid.z };
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                cur_bid = { bx, by, bz };
+                blk = BlockSync();
+                blk.alive = (int)nthreads;
+                for (unsigned wv = 0; wv < nwaves; wv++) {
+                    waves[wv] = WaveSync();
+                    unsigned lanes = nthreads - wv * 64;
+                    waves[wv].alive = lanes > 64 ? 64 : (int)lanes;
+                    memset(waves[wv].slot, 0, sizeof(waves[wv].slot));
+                }
+                for (unsigned t = 0; t < nthreads; t++) {
+                    Fiber &f = fibers[t];
+                    f.tid = { t % block.x, (t / block.x) % block.y, t / (block.x * block.y) };
+                    f.lane = (int)(t & 63);
+                    f.wave = &waves[t / 64];
+                    f.done = false;
+                    f.wait_ptr = nullptr;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = STACK;
+                    f.ctx.uc_link = &sched_ctx;
+                    makecontext(&f.ctx, fiber_main, 0);
+                }
+                unsigned remaining = nthreads;
+                while (remaining) {
+                    bool progressed = false;
+                    for (unsigned t = 0; t < nthreads; t++) {
+                        Fiber &f = fibers[t];
+                        if (f.done) continue;
+                        if (f.wait_ptr && *f.wait_ptr == f.wait_val) continue;
+                        f.wait_ptr = nullptr;
+                        cur = &f;
+                        cur_tid = f.tid;
+                        swapcontext(&sched_ctx, &f.ctx);
+                        progressed = true;
+                        if (f.done) remaining--;
+                    }
+                    if (!progressed) {
+                        fprintf(stderr, "emu: deadlock in block (%u,%u,%u): divergent collective?\n", bx, by, bz);
+                        abort();
+                    }
+                }
+            }
+    cur = nullptr;
+}
+
+}  // namespace emu
