@@ -1,0 +1,51 @@
+/*
+ * mrzgpu_host.h -- host driver of libmrzgpu.so: the `mrzip -n` file path built
+ * on the C ABI of mrzgpu.h.  It mirrors, for the rzip-only (-n) mode,
+ *   void rzip_fd(rzip_control *control, int fd_in, int fd_out)   (include/rzip.h:25, src/rzip.c:807-1132)
+ * together with what compress_file (src/mrzip.c:1053-1163) and the stream sink
+ * (src/stream.c:771-938 open_stream_out, :1574-1590 write_stream, :1307-1349
+ * flush_buffer, :1115-1305 compthread block writer, :1623-1648 close_stream_out)
+ * and write_magic (src/mrzip.c:127-188) add around it, so that the bytes
+ * written are identical to the reference's output file.
+ *
+ * mrz_control carries exactly the rzip_control fields that path reads
+ * (include/mrzip_private.h:419-524); names follow the reference.
+ */
+#ifndef MRZGPU_HOST_H
+#define MRZGPU_HOST_H
+
+#include "mrzgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int rzip_compression_level; /* -R / -L, 1..9 (src/main.c:575) */
+    int compression_level;      /* -L; only recorded in magic[18] (src/mrzip.c:171) */
+    int64_t window;             /* -w, units of 100 MiB; 0 = unset (src/rzip.c:883-884) */
+    int unlimited;              /* FLAG_UNLIMITED, -U (src/rzip.c:881-882) */
+    int64_t ramsize;            /* control->ramsize in bytes (-m * 100 MiB or sysconf) */
+    int64_t page_size;          /* control->page_size (4096) */
+    int hash_code;              /* control->hash_code; only 1 (MD5, the default) is supported */
+    int device;                 /* HIP device ordinal */
+} mrz_control;
+
+/* file -> file, as `mrzip -n -L<level> [-w|-U] -m<ramsize>` would write it.
+ * stats (may be NULL) receives the per-file totals printed at -vv. */
+int mrz_rzip_fd(const mrz_control *control, int fd_in, int fd_out, mrz_stats *stats);
+
+/* memory -> memory variant of the same path.  *out is malloc'd by the library
+ * (release with mrz_free); md5_out (may be NULL) gets the 16 trailing bytes. */
+int mrz_rzip_buffer(const mrz_control *control, const void *in, int64_t n, void **out, int64_t *out_len,
+                    mrz_stats *stats, uint8_t *md5_out);
+void mrz_free(void *p);
+
+/* chunking / block sizing rules alone (src/rzip.c:875-894, src/util.c:156-176,
+ * src/stream.c:797-914 for -n): returns max_chunk, *stream_bufsize optional */
+int64_t mrz_plan(const mrz_control *control, int64_t st_size, int64_t *stream_bufsize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,28 @@
+"""modern-rzip_amd -- MI355X-native rzip stage (long-range dedup pre-processor).
+
+The product is ``libmrzgpu.so`` (hand-written gfx950 HIP kernels behind the C
+ABI of ``include/mrzgpu.h``).  This package is only the Python-side plumbing
+used by tests and ``bench.py``: a ctypes binding whose names mirror the C ABI,
+which in turn mirrors the reference's ``rzip_fd`` / ``lz4_compresses`` /
+``blake2b_*`` interfaces.  There is no CPU fallback: using any operation
+without a loadable ``libmrzgpu.so`` and a HIP device raises.
+"""
+from .binding import (  # noqa: F401
+    MrzError,
+    RzipContext,
+    ChunkResult,
+    Stats,
+    Timings,
+    Control,
+    lib_path,
+    load_library,
+    chunk_bytes,
+    rzip_buffer,
+    MEM_HOST,
+    MEM_DEVICE,
+)
+
+__all__ = [
+    "MrzError", "RzipContext", "ChunkResult", "Stats", "Timings", "Control", "lib_path", "load_library",
+    "chunk_bytes", "rzip_buffer", "MEM_HOST", "MEM_DEVICE",
+]

@@ -1,0 +1,266 @@
+"""ctypes binding of libmrzgpu.so (include/mrzgpu.h).  Plumbing only."""
+import ctypes
+import os
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class MrzError(RuntimeError):
+    pass
+
+
+class Stats(ctypes.Structure):
+    """struct rzip_state.stats (include/mrzip_private.h:407-415)."""
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("inserts", "literals", "literal_bytes", "matches", "match_bytes", "tag_hits", "tag_misses")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class ChunkResult(ctypes.Structure):
+    _fields_ = [("s0_len", ctypes.c_int64), ("s1_len", ctypes.c_int64), ("crc32", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("d_s0", ctypes.c_void_p), ("d_s1", ctypes.c_void_p),
+                ("stats", Stats), ("min_mask", ctypes.c_int64), ("hash_count", ctypes.c_int64),
+                ("n_events", ctypes.c_int64)]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("tagscan_ms", ctypes.c_float), ("sequencer_ms", ctypes.c_float), ("encode_ms", ctypes.c_float),
+                ("crc_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("n_segments", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class Control(ctypes.Structure):
+    """The rzip_control fields rzip_fd reads for `mrzip -n` (include/mrzgpu_host.h)."""
+    _fields_ = [("rzip_compression_level", ctypes.c_int), ("compression_level", ctypes.c_int),
+                ("window", ctypes.c_int64), ("unlimited", ctypes.c_int), ("ramsize", ctypes.c_int64),
+                ("page_size", ctypes.c_int64), ("hash_code", ctypes.c_int), ("device", ctypes.c_int)]
+
+
+def lib_path():
+    return os.environ.get("MRZGPU_LIB", os.path.join(_HERE, "libmrzgpu.so"))
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libmrzgpu.so; raises MrzError if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise MrzError(f"{p} not found: build it with __graft_entry__.build() "
+                       f"(make -C modern-rzip_amd/csrc); there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.mrz_open.argtypes = [ctypes.POINTER(vp), ci, ci, i64]
+    lib.mrz_close.argtypes = [vp]
+    lib.mrz_close.restype = None
+    lib.mrz_strerror.argtypes = [ci]
+    lib.mrz_strerror.restype = ctypes.c_char_p
+    lib.mrz_last_hip_error.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p)]
+    lib.mrz_stream.argtypes = [vp]
+    lib.mrz_stream.restype = vp
+    lib.mrz_synchronize.argtypes = [vp]
+    lib.mrz_set_profiling.argtypes = [vp, ci]
+    lib.mrz_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    lib.mrz_rzip_chunk.argtypes = [vp, vp, i64, ci, ci, ctypes.POINTER(i64), ctypes.POINTER(ChunkResult)]
+    lib.mrz_fetch_streams.argtypes = [vp, vp, vp]
+    lib.mrz_chunk_bytes.argtypes = [i64]
+    lib.mrz_table_slots.argtypes = [vp]
+    lib.mrz_table_slots.restype = i64
+    lib.mrz_fetch_table.argtypes = [vp, vp]
+    lib.mrz_crc32.argtypes = [vp, vp, i64, ci, ctypes.POINTER(ctypes.c_uint32)]
+    if hasattr(lib, "mrz_lz4_compresses_batch"):
+        lib.mrz_lz4_compresses_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64), ci, ci, ci,
+                                                 ctypes.POINTER(ci)]
+        lib.mrz_lz4_compresses.argtypes = [vp, vp, i64, ci, ci, ctypes.POINTER(ci)]
+        lib.mrz_lz4_sizes.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ci), ci, ci, ctypes.POINTER(ci)]
+    if hasattr(lib, "mrz_blake2b_batch"):
+        lib.mrz_blake2b_init.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_size_t]
+        lib.mrz_blake2b_update.argtypes = [vp, vp, ctypes.c_size_t, ci]
+        lib.mrz_blake2b_final.argtypes = [vp, vp, ctypes.c_size_t]
+        lib.mrz_blake2b_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64), ci, ci, ctypes.c_size_t, vp]
+    if hasattr(lib, "mrz_rzip_buffer"):
+        lib.mrz_rzip_buffer.argtypes = [ctypes.POINTER(Control), vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                        ctypes.POINTER(Stats), vp]
+        lib.mrz_rzip_fd.argtypes = [ctypes.POINTER(Control), ci, ci, ctypes.POINTER(Stats)]
+        lib.mrz_free.argtypes = [vp]
+        lib.mrz_free.restype = None
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc, ctx=None):
+    if rc == 0:
+        return
+    msg = lib.mrz_strerror(rc).decode()
+    if ctx is not None:
+        txt = ctypes.c_char_p()
+        code = lib.mrz_last_hip_error(ctx, ctypes.byref(txt))
+        if code:
+            msg += f" (hip error {code}: {txt.value.decode() if txt.value else '?'})"
+    raise MrzError(f"libmrzgpu: {msg} [{rc}]")
+
+
+def chunk_bytes(chunk_size, lib=None):
+    return (lib or load_library()).mrz_chunk_bytes(chunk_size)
+
+
+def _as_ptr(buf):
+    """(pointer, length, where, keepalive) for bytes-like / (device_ptr, n) inputs."""
+    if isinstance(buf, tuple):  # (device pointer as int, nbytes)
+        return ctypes.c_void_p(buf[0]), int(buf[1]), MEM_DEVICE, None
+    if hasattr(buf, "data_ptr"):  # torch tensor (uint8, contiguous)
+        n = buf.numel() * buf.element_size()
+        where = MEM_DEVICE if buf.is_cuda else MEM_HOST
+        return ctypes.c_void_p(buf.data_ptr()), n, where, buf
+    b = bytes(buf) if not isinstance(buf, (bytes, bytearray)) else buf
+    if isinstance(b, bytearray):
+        arr = (ctypes.c_uint8 * len(b)).from_buffer(b)
+        return ctypes.cast(arr, ctypes.c_void_p), len(b), MEM_HOST, arr
+    return ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p), len(b), MEM_HOST, b
+
+
+class RzipContext:
+    """One mrz_ctx: the per-file half of rzip_fd (src/rzip.c:836-913)."""
+
+    def __init__(self, level=7, max_chunk=0, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.ctx = ctypes.c_void_p()
+        _check(self.lib, self.lib.mrz_open(ctypes.byref(self.ctx), device, level, max_chunk))
+        self.level = level
+        self.victim_round = 0  # static victim_round of insert_hash (src/rzip.c:259)
+
+    def close(self):
+        if self.ctx:
+            self.lib.mrz_close(self.ctx)
+            self.ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self.lib.mrz_stream(self.ctx)
+
+    def set_profiling(self, on=True):
+        _check(self.lib, self.lib.mrz_set_profiling(self.ctx, 1 if on else 0), self.ctx)
+
+    def timings(self):
+        t = Timings()
+        _check(self.lib, self.lib.mrz_get_timings(self.ctx, ctypes.byref(t)), self.ctx)
+        return t
+
+    def rzip_chunk(self, chunk, chunk_bytes_=None, fetch=True):
+        """hash_search over one chunk.  Returns (ChunkResult, s0 bytes, s1 bytes)."""
+        ptr, n, where, keep = _as_ptr(chunk)
+        cb = chunk_bytes_ or self.lib.mrz_chunk_bytes(n)
+        res = ChunkResult()
+        vr = ctypes.c_int64(self.victim_round)
+        _check(self.lib, self.lib.mrz_rzip_chunk(self.ctx, ptr, n, where, cb, ctypes.byref(vr), ctypes.byref(res)),
+               self.ctx)
+        self.victim_round = vr.value
+        if not fetch:
+            return res, None, None
+        s0 = ctypes.create_string_buffer(max(1, res.s0_len))
+        s1 = ctypes.create_string_buffer(max(1, res.s1_len))
+        _check(self.lib, self.lib.mrz_fetch_streams(self.ctx, s0, s1), self.ctx)
+        return res, s0.raw[:res.s0_len], s1.raw[:res.s1_len]
+
+    def fetch_table(self):
+        n = self.lib.mrz_table_slots(self.ctx)
+        buf = ctypes.create_string_buffer(n * 16)
+        _check(self.lib, self.lib.mrz_fetch_table(self.ctx, buf), self.ctx)
+        return buf.raw
+
+    def crc32(self, data):
+        ptr, n, where, keep = _as_ptr(data)
+        out = ctypes.c_uint32()
+        _check(self.lib, self.lib.mrz_crc32(self.ctx, ptr, n, where, ctypes.byref(out)), self.ctx)
+        return out.value
+
+    # ---- LZ4 gate (src/stream.c:1685-1733) ----
+    def lz4_compresses(self, blocks, threshold=100):
+        single = isinstance(blocks, (bytes, bytearray)) or hasattr(blocks, "data_ptr")
+        blks = [blocks] if single else list(blocks)
+        prep = [_as_ptr(b) for b in blks]
+        if not prep:
+            return []
+        where = prep[0][2]
+        ptrs = (ctypes.c_void_p * len(prep))(*[p[0] for p in prep])
+        lens = (ctypes.c_int64 * len(prep))(*[p[1] for p in prep])
+        out = (ctypes.c_int * len(prep))()
+        _check(self.lib, self.lib.mrz_lz4_compresses_batch(self.ctx, ptrs, lens, len(prep), where, threshold, out),
+               self.ctx)
+        return out[0] if single else list(out)
+
+    def lz4_sizes(self, blocks):
+        prep = [_as_ptr(b) for b in blocks]
+        if not prep:
+            return []
+        ptrs = (ctypes.c_void_p * len(prep))(*[p[0] for p in prep])
+        lens = (ctypes.c_int * len(prep))(*[p[1] for p in prep])
+        out = (ctypes.c_int * len(prep))()
+        _check(self.lib, self.lib.mrz_lz4_sizes(self.ctx, ptrs, lens, len(prep), prep[0][2], out), self.ctx)
+        return list(out)
+
+    # ---- BLAKE2b (common/blake2b.h:47-49) ----
+    def blake2b(self, data, outlen=64, pieces=None):
+        st = ctypes.c_void_p()
+        _check(self.lib, self.lib.mrz_blake2b_init(self.ctx, ctypes.byref(st), outlen), self.ctx)
+        parts = pieces if pieces is not None else [data]
+        for part in parts:
+            ptr, n, where, keep = _as_ptr(part)
+            _check(self.lib, self.lib.mrz_blake2b_update(st, ptr, n, where), self.ctx)
+        out = ctypes.create_string_buffer(outlen)
+        _check(self.lib, self.lib.mrz_blake2b_final(st, out, outlen), self.ctx)
+        return out.raw
+
+    def blake2b_batch(self, msgs, outlen=64):
+        prep = [_as_ptr(m) for m in msgs]
+        if not prep:
+            return []
+        ptrs = (ctypes.c_void_p * len(prep))(*[p[0] for p in prep])
+        lens = (ctypes.c_int64 * len(prep))(*[p[1] for p in prep])
+        out = ctypes.create_string_buffer(outlen * len(prep))
+        _check(self.lib, self.lib.mrz_blake2b_batch(self.ctx, ptrs, lens, len(prep), prep[0][2], outlen, out),
+               self.ctx)
+        return [out.raw[i * outlen:(i + 1) * outlen] for i in range(len(prep))]
+
+
+def rzip_buffer(data, level=7, window=0, unlimited=False, ramsize=60 << 30, device=0, lib=None):
+    """`mrzip -n -L<level>` of an in-memory file through the C host driver
+    (mrz_rzip_buffer: rzip_fd + the -n stream sink + write_magic).
+    Returns (archive bytes, Stats, md5 bytes)."""
+    lib = lib or load_library()
+    ctl = Control(level, level, window, 1 if unlimited else 0, ramsize, 4096, 1, device)
+    ptr, n, where, keep = _as_ptr(data)
+    if where != MEM_HOST:
+        raise MrzError("rzip_buffer takes host memory")
+    out = ctypes.c_void_p()
+    out_len = ctypes.c_int64()
+    st = Stats()
+    md5 = ctypes.create_string_buffer(16)
+    _check(lib, lib.mrz_rzip_buffer(ctypes.byref(ctl), ptr, n, ctypes.byref(out), ctypes.byref(out_len),
+                                    ctypes.byref(st), md5))
+    try:
+        return ctypes.string_at(out, out_len.value), st, md5.raw
+    finally:
+        lib.mrz_free(out)

@@ -6,50 +6,9 @@
 #include <string.h>
 
 #include "../../include/mrzgpu.h"
-#include "mrz_kernels.h"
+#include "mrz_ctx.h"
 
-// positions per segment: tags 8 B/position -> 128 MiB scratch, bitmap 2 MiB
-#define MRZ_SEG_POSITIONS (16ll << 20)
 
-struct mrz_ctx {
-    int device;
-    int level;
-    unsigned mb_used, initial_freq, max_chain;
-    int hash_bits;
-    int64_t nslots;
-    hipStream_t stream;
-    hipError_t last_err;
-    int profiling;
-    mrz_timings timings;
-
-    int64_t h_index[256];
-    int64_t *d_index;
-    mrz_slot *d_tab;
-    mrz_seq_state *d_state;
-    int64_t *d_tags;
-    uint16_t *d_bitmap;
-    mrz_event *d_events;
-    int64_t event_cap;
-    int64_t *d_block_s0, *d_block_s1;
-    int64_t block_cap, block1_cap;
-    int64_t *d_lit_off;
-    int64_t lit_off_cap;
-    mrz_enc_totals *d_totals;
-    uint8_t *d_s0, *d_s1;
-    int64_t s0_cap, s1_cap;
-    int64_t s0_len, s1_len;
-    uint8_t *d_in;  // staging for host-resident chunks
-    int64_t in_cap;
-    mrz_crc_tables *d_crc_tables;
-    uint32_t *d_crc_parts;
-    int64_t crc_parts_cap;
-    uint32_t *d_crc_out;
-    int have_chunk;
-
-    // LZ4 / BLAKE2b scratch lives in their own translation units
-    void *lz4_scratch;
-    void *b2_scratch;
-};
 
 // levels[] rows {mb_used, initial_freq, max_chain_len}, src/rzip.c:65-73
 static const unsigned k_levels[10][3] = { { 1, 4, 1 },  { 2, 4, 2 },  { 4, 4, 2 },   { 8, 4, 2 },   { 16, 4, 3 },
@@ -79,35 +38,6 @@ static void mrz_make_hash_index(int64_t H[256]) {
         if (k >= 0) draw[k] = s >> 1;
     }
     for (int i = 0; i < 256; i++) H[i] = ((int64_t)draw[2 * i] << 16) ^ (int64_t)draw[2 * i + 1];
-}
-
-#define HIPCHK(ctx, expr)                     \
-    do {                                      \
-        hipError_t e__ = (expr);              \
-        if (e__ != hipSuccess) {              \
-            (ctx)->last_err = e__;            \
-            return MRZ_E_HIP;                 \
-        }                                     \
-    } while (0)
-
-template <typename T>
-static int mrz_grow(mrz_ctx *ctx, T **ptr, int64_t *cap, int64_t want) {
-    if (want <= *cap && *ptr) return MRZ_OK;
-    if (*ptr) {
-        hipFree(*ptr);
-        *ptr = nullptr;
-        *cap = 0;
-    }
-    int64_t ask = want < 16 ? 16 : want;
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, (size_t)ask * sizeof(T));
-    if (e != hipSuccess) {
-        ctx->last_err = e;
-        return MRZ_E_NOMEM;
-    }
-    *ptr = (T *)p;
-    *cap = ask;
-    return MRZ_OK;
 }
 
 extern "C" int mrz_abi_version(void) { return MRZ_ABI_VERSION; }
@@ -159,6 +89,7 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_crc_out);
     if (ctx->lz4_scratch) hipFree(ctx->lz4_scratch);
     if (ctx->b2_scratch) hipFree(ctx->b2_scratch);
+    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -257,7 +188,7 @@ extern "C" int mrz_fetch_table(mrz_ctx *ctx, void *host_dst) {
 }
 
 // resolves a caller buffer to a device pointer (staging host memory)
-static int mrz_stage_input(mrz_ctx *ctx, const void *buf, int64_t n, int where, const uint8_t **dev) {
+int mrz_stage_input(mrz_ctx *ctx, const void *buf, int64_t n, int where, const uint8_t **dev) {
     if (where == MRZ_MEM_DEVICE) {
         *dev = (const uint8_t *)buf;
         return MRZ_OK;

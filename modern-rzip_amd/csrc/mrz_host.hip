@@ -1,0 +1,354 @@
+// mrz_host.hip -- host driver (include/mrzgpu_host.h): the `mrzip -n` file path
+// around the GPU rzip stage.  Host code only: chunk loop, -n stream sink and
+// block framing, magic header, whole-file MD5 on a helper thread (the
+// reference also keeps the checksums off the matcher's thread,
+// src/rzip.c:488-505).  MD5 is a strictly serial hash; it overlaps the GPU work.
+#include <errno.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <thread>
+#include <vector>
+
+#include "../../include/mrzgpu_host.h"
+#include "mrz_ctx.h"
+
+namespace {
+
+const int64_t kMiB = 1048576;
+const int64_t kStreamMin = 10 * kMiB;   // STREAM_BUFSIZE, include/mrzip_private.h:27
+const int64_t kChunkUnit = 100 * kMiB;  // CHUNK_MULTIPLE, src/rzip.c:46
+
+// ---- MD5 (RFC 1321; libgcrypt GCRY_MD_MD5 in the reference) ---------------
+struct Md5 {
+    uint32_t h[4];
+    uint64_t total;
+    uint8_t pend[64];
+    size_t npend;
+    Md5() : total(0), npend(0) {
+        h[0] = 0x67452301u;
+        h[1] = 0xefcdab89u;
+        h[2] = 0x98badcfeu;
+        h[3] = 0x10325476u;
+    }
+    static uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+    void block(const uint8_t *p) {
+        static const uint32_t K[64] = {
+            0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+            0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+            0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+            0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+            0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+            0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+            0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+            0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391 };
+        static const int S[4][4] = { { 7, 12, 17, 22 }, { 5, 9, 14, 20 }, { 4, 11, 16, 23 }, { 6, 10, 15, 21 } };
+        uint32_t m[16];
+        memcpy(m, p, 64);  // little-endian host
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+        for (int i = 0; i < 64; i++) {
+            const int r = i >> 4;
+            uint32_t f;
+            int g;
+            switch (r) {
+                case 0: f = d ^ (b & (c ^ d)); g = i; break;
+                case 1: f = c ^ (d & (b ^ c)); g = (5 * i + 1) & 15; break;
+                case 2: f = b ^ c ^ d; g = (3 * i + 5) & 15; break;
+                default: f = c ^ (b | ~d); g = (7 * i) & 15; break;
+            }
+            const uint32_t nb = b + rol(a + f + K[i] + m[g], S[r][i & 3]);
+            a = d;
+            d = c;
+            c = b;
+            b = nb;
+        }
+        h[0] += a;
+        h[1] += b;
+        h[2] += c;
+        h[3] += d;
+    }
+    void update(const uint8_t *p, size_t n) {
+        total += n;
+        if (npend) {
+            size_t take = 64 - npend;
+            if (take > n) take = n;
+            memcpy(pend + npend, p, take);
+            npend += take;
+            p += take;
+            n -= take;
+            if (npend < 64) return;
+            block(pend);
+            npend = 0;
+        }
+        for (; n >= 64; p += 64, n -= 64) block(p);
+        if (n) {
+            memcpy(pend, p, n);
+            npend = n;
+        }
+    }
+    void finish(uint8_t out[16]) {
+        const uint64_t bits = total * 8;
+        uint8_t tail[128];
+        size_t k = npend;
+        memcpy(tail, pend, k);
+        tail[k++] = 0x80;
+        while (k % 64 != 56) tail[k++] = 0;
+        for (int i = 0; i < 8; i++) tail[k++] = (uint8_t)(bits >> (8 * i));
+        for (size_t o = 0; o < k; o += 64) block(tail + o);
+        memcpy(out, h, 16);
+    }
+};
+
+int64_t page_floor(int64_t v, int64_t page) {  // round_to_page, src/util.c:166-169
+    v -= v % page;
+    return v ? v : page;
+}
+int64_t page_ceil(int64_t v, int64_t page) {  // round_up_page, src/util.c:171-176
+    const int64_t r = v % page;
+    return r ? v + page - r : v;
+}
+
+// ---- the -n stream sink ----------------------------------------------------
+// Two logical streams are cut into blocks whenever a stream buffer of
+// `bufsize` bytes fills (write_stream / flush_buffer), blocks are appended to
+// the file in flush order, each with a {ctype, c_len, u_len, next} header whose
+// `next` field is patched when the following block of the same stream lands
+// (compthread, src/stream.c:1199-1293).
+struct Sink {
+    std::vector<uint8_t> &out;
+    int64_t bufsize;
+    int cb = 1;
+    int eof = 0;
+    int64_t size_field = 0;
+    int64_t initial_pos = 0, cur_pos = 0;
+    int64_t last_head[2] = { 0, 0 };
+    int blocks = 0;
+    std::vector<uint8_t> sbuf[2];
+
+    Sink(std::vector<uint8_t> &o, int64_t bs) : out(o), bufsize(bs) {}
+
+    void put_val(int64_t v, int width) {
+        for (int i = 0; i < width; i++) out.push_back((uint8_t)((uint64_t)v >> (8 * i)));
+    }
+    void begin_chunk(int64_t chunk_size, int chunk_bytes, int is_last, int64_t page) {
+        cb = chunk_bytes;
+        eof = is_last;
+        size_field = chunk_size < page ? page : chunk_size;  // src/stream.c:779-780
+        cur_pos = 0;
+        blocks = 0;
+        sbuf[0].clear();
+        sbuf[1].clear();
+    }
+    void emit_block(int s) {
+        if (!blocks++) {
+            out.push_back((uint8_t)cb);
+            out.push_back((uint8_t)eof);
+            put_val(size_field, cb);
+            initial_pos = (int64_t)out.size();
+            for (int j = 0; j < 2; j++) {
+                last_head[j] = cur_pos + 1 + 2 * cb;
+                out.push_back(3);  // CTYPE_NONE
+                put_val(0, cb);
+                put_val(0, cb);
+                put_val(0, cb);
+                cur_pos += 1 + 3 * cb;
+            }
+        }
+        for (int i = 0; i < cb; i++)
+            out[(size_t)(initial_pos + last_head[s] + i)] = (uint8_t)((uint64_t)cur_pos >> (8 * i));
+        last_head[s] = cur_pos + 1 + 2 * cb;
+        const int64_t len = (int64_t)sbuf[s].size();
+        out.push_back(3);
+        put_val(len, cb);
+        put_val(len, cb);
+        put_val(0, cb);
+        cur_pos += 1 + 3 * cb;
+        out.insert(out.end(), sbuf[s].begin(), sbuf[s].end());
+        cur_pos += len;
+        sbuf[s].clear();
+    }
+    void write(int s, const uint8_t *p, int64_t n) {
+        while (n) {
+            const int64_t room = bufsize - (int64_t)sbuf[s].size();
+            const int64_t take = room < n ? room : n;
+            sbuf[s].insert(sbuf[s].end(), p, p + take);
+            p += take;
+            n -= take;
+            if ((int64_t)sbuf[s].size() == bufsize) emit_block(s);
+        }
+    }
+    // Replays the chunk's records so "buffer full" events of the two streams
+    // interleave as in the reference: the stream-1 bytes of a literal follow
+    // its 3-byte header (put_literal, src/rzip.c:213-227).
+    int feed(const uint8_t *s0, int64_t n0, const uint8_t *s1, int64_t n1) {
+        int64_t i = 0, j = 0;
+        while (i < n0) {
+            if (i + 3 > n0) return MRZ_E_STATE;
+            const int head = s0[i];
+            const int64_t len = s0[i + 1] | (int64_t)s0[i + 2] << 8;
+            if (head == 0) {
+                write(0, s0 + i, 3);
+                i += 3;
+                if (len == 0) {
+                    if (i + 4 != n0) return MRZ_E_STATE;
+                    write(0, s0 + i, 4);
+                    i += 4;
+                    break;
+                }
+                if (j + len > n1) return MRZ_E_STATE;
+                write(1, s1 + j, len);
+                j += len;
+            } else {
+                if (i + 3 + cb > n0) return MRZ_E_STATE;
+                write(0, s0 + i, 3 + cb);
+                i += 3 + cb;
+            }
+        }
+        if (j != n1) return MRZ_E_STATE;
+        emit_block(0);  // close_stream_out flushes both, even when empty
+        emit_block(1);
+        return MRZ_OK;
+    }
+};
+
+int run_file(const mrz_control *ctl, const uint8_t *in, int64_t n, std::vector<uint8_t> &out, mrz_stats *stats,
+             uint8_t *md5_out) {
+    if (!ctl || ctl->rzip_compression_level < 1 || ctl->rzip_compression_level > 9 || n < 0) return MRZ_E_ARG;
+    if (ctl->hash_code != 1 && ctl->hash_code != 0) return MRZ_E_ARG;  // MD5 only (reference default)
+    const int64_t page = ctl->page_size > 0 ? ctl->page_size : 4096;
+    int64_t bufsize = 0;
+    const int64_t max_chunk = mrz_plan(ctl, n, &bufsize);
+
+    // whole-file hash on a helper thread while the GPU works (src/rzip.c:1069-1090)
+    uint8_t md5[16];
+    std::thread hasher([&]() {
+        Md5 h;
+        h.update(in, (size_t)n);
+        h.finish(md5);
+    });
+
+    mrz_ctx *ctx = nullptr;
+    int rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, max_chunk < n ? max_chunk : n);
+    mrz_stats total;
+    memset(&total, 0, sizeof(total));
+    out.clear();
+    out.resize(20, 0);  // header placeholder (compress_file, src/mrzip.c:1126)
+    if (!rc) {
+        Sink sink(out, bufsize);
+        std::vector<uint8_t> s0, s1;
+        int64_t victim_round = 0;  // first rzip_fd call of the process
+        int64_t left = n, pos = 0;
+        int pass = 0;
+        while (!rc && (!pass || left > 0)) {  // chunk loop, src/rzip.c:915-1061
+            const int64_t csz = max_chunk < left ? max_chunk : left;
+            const int cb = mrz_chunk_bytes(csz);
+            mrz_chunk_result res;
+            rc = mrz_rzip_chunk(ctx, in + pos, csz, MRZ_MEM_HOST, cb, &victim_round, &res);
+            if (rc) break;
+            s0.resize((size_t)res.s0_len);
+            s1.resize((size_t)res.s1_len);
+            rc = mrz_fetch_streams(ctx, s0.data(), s1.data());
+            if (rc) break;
+            total.inserts += res.stats.inserts;
+            total.literals += res.stats.literals;
+            total.literal_bytes += res.stats.literal_bytes;
+            total.matches += res.stats.matches;
+            total.match_bytes += res.stats.match_bytes;
+            total.tag_hits += res.stats.tag_hits;
+            total.tag_misses += res.stats.tag_misses;
+            sink.begin_chunk(csz, cb, csz == left, page);
+            rc = sink.feed(s0.data(), res.s0_len, s1.data(), res.s1_len);
+            pos += csz;
+            left -= csz;
+            pass++;
+        }
+    }
+    hasher.join();
+    if (ctx) mrz_close(ctx);
+    if (rc) return rc;
+    out.insert(out.end(), md5, md5 + 16);
+    // write_magic, src/mrzip.c:127-188
+    uint8_t *mg = out.data();
+    mg[0] = 'M';
+    mg[1] = 'R';
+    mg[2] = 'Z';
+    mg[3] = 'I';
+    mg[4] = 0;  // MRZIP_MAJOR
+    mg[5] = 9;  // MRZIP_MINOR
+    for (int i = 0; i < 8; i++) mg[6 + i] = (uint8_t)((uint64_t)n >> (8 * i));
+    mg[14] = 1;  // hash_code: MD5
+    mg[18] = (uint8_t)((ctl->rzip_compression_level << 4) + ctl->compression_level);
+    if (stats) *stats = total;
+    if (md5_out) memcpy(md5_out, md5, 16);
+    return MRZ_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mrz_plan(const mrz_control *ctl, int64_t st_size, int64_t *stream_bufsize) {
+    const int64_t page = ctl->page_size > 0 ? ctl->page_size : 4096;
+    const int64_t usable = ctl->ramsize / 3;  // setup_ram, src/util.c:156-164 (file -> file)
+    int64_t max_chunk;                        // src/rzip.c:881-888
+    if (ctl->unlimited)
+        max_chunk = st_size;
+    else if (ctl->window)
+        max_chunk = ctl->window * kChunkUnit;
+    else
+        max_chunk = ctl->ramsize / 3 * 2;
+    if (max_chunk < st_size) max_chunk = page_floor(max_chunk, page);
+    if (stream_bufsize) {  // open_stream_out with NO_COMPRESS, src/stream.c:797-805,878-881,913-914
+        const int64_t first = st_size < max_chunk ? st_size : max_chunk;
+        const int64_t chunk_limit = first < page ? page : first;
+        int64_t limit = usable;
+        if (st_size > 0 && st_size < limit)
+            limit = st_size > kStreamMin ? st_size : kStreamMin;
+        else if (limit > chunk_limit)
+            limit = chunk_limit;
+        *stream_bufsize = page_ceil(limit, page);
+    }
+    return max_chunk;
+}
+
+extern "C" void mrz_free(void *p) { free(p); }
+
+extern "C" int mrz_rzip_buffer(const mrz_control *ctl, const void *in, int64_t n, void **out, int64_t *out_len,
+                               mrz_stats *stats, uint8_t *md5_out) {
+    if (!out || !out_len || (n > 0 && !in)) return MRZ_E_ARG;
+    std::vector<uint8_t> buf;
+    const int rc = run_file(ctl, (const uint8_t *)in, n, buf, stats, md5_out);
+    if (rc) return rc;
+    void *p = malloc(buf.size() ? buf.size() : 1);
+    if (!p) return MRZ_E_NOMEM;
+    memcpy(p, buf.data(), buf.size());
+    *out = p;
+    *out_len = (int64_t)buf.size();
+    return MRZ_OK;
+}
+
+extern "C" int mrz_rzip_fd(const mrz_control *ctl, int fd_in, int fd_out, mrz_stats *stats) {
+    // read the whole input (the reference mmaps it, src/rzip.c:956)
+    std::vector<uint8_t> in;
+    uint8_t tmp[1 << 16];
+    for (;;) {
+        const ssize_t r = read(fd_in, tmp, sizeof(tmp));
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return MRZ_E_ARG;
+        }
+        if (r == 0) break;
+        in.insert(in.end(), tmp, tmp + r);
+    }
+    std::vector<uint8_t> buf;
+    const int rc = run_file(ctl, in.data(), (int64_t)in.size(), buf, stats, nullptr);
+    if (rc) return rc;
+    size_t off = 0;
+    while (off < buf.size()) {
+        const ssize_t w = write(fd_out, buf.data() + off, buf.size() - off);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return MRZ_E_ARG;
+        }
+        off += (size_t)w;
+    }
+    return MRZ_OK;
+}

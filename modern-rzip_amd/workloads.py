@@ -1,0 +1,68 @@
+"""Seeded synthetic workloads of SURVEY.md section 8d (no downloads: enwik8 is
+not available offline).  Host generators return bytes; *_device build the large
+BASELINE configurations directly in HBM with torch (plumbing only)."""
+import numpy as np
+
+
+def zipf_text(nbytes, seed=7, vocab=5000):
+    """S1-style text: Zipf(1/rank) words from a seeded vocabulary, space
+    separated, a newline every 20000 words."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 11, size=vocab)
+    words = [bytes(rng.integers(97, 123, size=int(k), dtype=np.uint8)) for k in lens]
+    w = 1.0 / np.arange(1, vocab + 1)
+    w /= w.sum()
+    out = bytearray()
+    while len(out) < nbytes:
+        idx = rng.choice(vocab, size=20000, p=w)
+        for i in idx:
+            out += words[i]
+            out += b" "
+        out[-1:] = b"\n"
+    return bytes(out[:nbytes])
+
+
+def rep64k(nperiods, seed=1234, period=65536, first_period=0):
+    """S2 "rep64k": a `period`-byte text block repeated; in period i the byte at
+    (37*i) % period is replaced by i & 0xff."""
+    base = np.frombuffer(zipf_text(period, seed=seed), dtype=np.uint8)
+    arr = np.tile(base, nperiods).reshape(nperiods, period).copy()
+    i = np.arange(first_period, first_period + nperiods)
+    arr[np.arange(nperiods), (37 * i) % period] = (i & 0xFF).astype(np.uint8)
+    return arr.tobytes()
+
+
+def rep64k_device(nperiods, device, seed=1234, period=65536):
+    """The same stream built in HBM: returns a uint8 torch tensor of nperiods*period bytes."""
+    import torch
+    base = torch.frombuffer(bytearray(zipf_text(period, seed=seed)), dtype=torch.uint8).to(device)
+    out = base.repeat(nperiods).view(nperiods, period)
+    i = torch.arange(nperiods, device=device, dtype=torch.int64)
+    out[i, (37 * i) % period] = (i & 0xFF).to(torch.uint8)
+    return out.view(-1)
+
+
+def noise(nbytes, seed=99):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+
+
+def tar_like(nbytes, seed=5):
+    """S3-style mix: text members, noise members and exact duplicates of earlier
+    members, 512-byte aligned."""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    members = []
+    while len(out) < nbytes:
+        kind = rng.random()
+        size = int(2 ** rng.uniform(10, 17))
+        if kind < 0.6 or not members:
+            mem = zipf_text(size, seed=int(rng.integers(1, 1 << 30)))
+        elif kind < 0.85:
+            mem = noise(size, seed=int(rng.integers(1, 1 << 30)))
+        else:
+            mem = members[int(rng.integers(0, len(members)))]
+        members.append(mem)
+        out += mem
+        out += bytes((-len(out)) % 512)
+    return bytes(out[:nbytes])

@@ -1,0 +1,35 @@
+"""Shared parity checks: libmrzgpu (real or emulated) against the oracle."""
+import hashlib
+
+import modern_rzip_amd as m
+
+
+def check_chunk(lib, oracle, data, level=7, victim_round=0, table=False):
+    """mrz_rzip_chunk vs mrzo_rzip_chunk: both streams, CRC, the seven counters,
+    victim_round, final mask / hash_count (and optionally the whole table)."""
+    want = oracle.rzip_chunk(data, level=level, victim_round=victim_round, want_table=table)
+    with m.RzipContext(level=level, max_chunk=len(data), lib=lib) as ctx:
+        ctx.victim_round = victim_round
+        res, s0, s1 = ctx.rzip_chunk(data)
+        assert res.crc32 == want["crc"]
+        assert res.stats.as_dict() == want["stats"]
+        assert ctx.victim_round == want["victim_round"]
+        assert res.min_mask == want["min_mask"]
+        assert res.hash_count == want["hash_count"]
+        assert s1 == want["s1"]
+        assert s0 == want["s0"]
+        if table:
+            assert ctx.fetch_table() == want["table"]
+    return want
+
+
+def check_file(lib, oracle, data, level=7, **kw):
+    """Host driver (rzip_fd mirror) vs oracle whole-file output, plus decode."""
+    want, wstats, wmd5 = oracle.compress(data, level=level, **kw)
+    got, gstats, gmd5 = m.rzip_buffer(data, level=level, lib=lib, **kw)
+    assert gmd5 == wmd5 == hashlib.md5(data).digest()
+    assert gstats.as_dict() == wstats
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+    rc, back = oracle.decompress(got)
+    assert rc == 0 and back == data
+    return got

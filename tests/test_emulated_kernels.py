@@ -1,0 +1,110 @@
+"""CPU tier: the gfx950 kernel SOURCES compiled by g++ against the wave64
+emulator (tests/emu) and driven through the same C ABI, checked against the
+oracle.  This exercises the kernels' logic (ballot/shuffle algorithms, indexing,
+bounds) where sanitizers and debuggers work; the GPU tier repeats the same
+checks on the real library at larger sizes."""
+import hashlib
+import json
+import os
+import zlib
+
+import pytest
+
+import modern_rzip_amd as m
+from tests import _parity, _util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "vectors.json")) as f:
+    GOLD = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return _util.golden_inputs()
+
+
+@pytest.mark.parametrize("name", ["empty", "range30", "a1000", "range256x64", "seed42x64"])
+def test_golden_files_through_host_driver(emu_lib, oracle, inputs, name):
+    got = _parity.check_file(emu_lib, oracle, inputs[name])
+    assert hashlib.sha256(got).hexdigest() == GOLD["files"][name]["sha256"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 30, 31, 32, 33, 62, 63, 64, 95, 4095, 4096, 4097, 4127])
+def test_ragged_sizes(emu_lib, oracle, n):
+    _parity.check_chunk(emu_lib, oracle, (_util.zipf_text(max(n, 1), seed=n + 1) * 2)[:n])
+
+
+def test_periodic_text_levels(emu_lib, oracle):
+    data = _util.rep64k(3, seed=5, period=8192)
+    for level in (1, 4, 6, 7, 9):
+        _parity.check_chunk(emu_lib, oracle, data, level=level)
+
+
+def test_victim_round_chain(emu_lib, oracle):
+    data = _util.rep64k(24, seed=9, period=2048)
+    for vr in (0, 3, 15):
+        _parity.check_chunk(emu_lib, oracle, data, victim_round=vr)
+
+
+def test_noise_and_table_state(emu_lib, oracle):
+    _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(40000, seed=3), table=True)
+
+
+def test_backward_extension_near_start(emu_lib, oracle):
+    # a repeat whose backward extension runs into offset 0 and into last_match
+    blk = _util.xorshift_noise(700, seed=8)
+    _parity.check_chunk(emu_lib, oracle, blk + blk + b"xyz" + blk[5:] + blk)
+
+
+def test_long_match_pieces(emu_lib, oracle):
+    # one match longer than 0xFFFF: put_match splits it (src/rzip.c:183)
+    blk = _util.xorshift_noise(70000, seed=12)
+    _parity.check_chunk(emu_lib, oracle, blk + blk)
+
+
+def test_crc32_kernel(emu_lib):
+    with m.RzipContext(lib=emu_lib) as ctx:
+        for n in (0, 1, 15, 16, 17, 1000, 65535, 65536, 65537, 3 * 65536 + 77):
+            d = _util.xorshift_noise(n, seed=n + 5)
+            assert ctx.crc32(d) == zlib.crc32(d), n
+
+
+def test_blake2b_kernels(emu_lib, oracle):
+    with m.RzipContext(lib=emu_lib) as ctx:
+        msgs = [_util.xorshift_noise(n, seed=n + 1) for n in (0, 1, 127, 128, 129, 256, 257, 1000)]
+        for outlen in (64, 32):
+            got = ctx.blake2b_batch(msgs, outlen)
+            assert got == [hashlib.blake2b(x, digest_size=outlen).digest() for x in msgs]
+        d = _util.xorshift_noise(223 * 9 + 40, seed=2)
+        rows = [d[i:i + 223] for i in range(0, len(d), 223)]
+        assert ctx.blake2b(d, pieces=rows) == hashlib.blake2b(d).digest()
+        assert ctx.blake2b(b"") == hashlib.blake2b(b"").digest()
+        assert ctx.blake2b(d, pieces=[d[:128], d[128:256], d[256:]]) == oracle.blake2b(d)
+
+
+def test_lz4_kernel_sizes(emu_lib, oracle):
+    with open(os.path.join(HERE, "golden", "lz4_sizes.json")) as f:
+        gold = json.load(f)["sizes"]
+    from tests.golden import make_lz4_golden
+    small = [(k, d) for k, d in make_lz4_golden.cases() if len(d) <= 70000]
+    with m.RzipContext(lib=emu_lib) as ctx:
+        got = ctx.lz4_sizes([d for _, d in small])
+        for (name, d), g in zip(small, got):
+            assert g == gold[name] == oracle.lz4_size(d), name
+        extra = [bytes(n) for n in (1, 12, 13, 14, 64)] + [_util.zipf_text(n, seed=n) for n in (13, 20, 100, 3000)]
+        assert ctx.lz4_sizes(extra) == [oracle.lz4_size(d) for d in extra]
+
+
+def test_lz4_gate(emu_lib, oracle):
+    blocks = [_util.zipf_text(30000, seed=4), _util.xorshift_noise(30000, seed=4), bytes(5000),
+              _util.xorshift_noise(20000, seed=5) + _util.zipf_text(10000, seed=6)]
+    with m.RzipContext(lib=emu_lib) as ctx:
+        for thr in (100, 60, 10):
+            assert ctx.lz4_compresses(blocks, thr) == [oracle.lz4_compresses(b, thr) for b in blocks]
+        assert ctx.lz4_compresses(blocks[0]) == oracle.lz4_compresses(blocks[0], 100)
+
+
+def test_two_chunks_through_host_driver(emu_lib, oracle):
+    data = _util.rep64k(6, seed=13, period=4096)
+    # ramsize chosen so that max_chunk (= ramsize/3*2, page-rounded) splits the file in two
+    _parity.check_file(emu_lib, oracle, data, ramsize=3 * 16384 // 2 + 3000)

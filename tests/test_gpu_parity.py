@@ -1,0 +1,182 @@
+"""GPU tier (-m gpu): libmrzgpu.so on a real MI355X through the C ABI, bit-exact
+against the oracle on seeded inputs, against the reference's golden vectors, and
+-- at sizes the oracle cannot reach quickly -- through size-independent
+properties (decode round trip, CRC/MD5 equality, stream accounting)."""
+import hashlib
+import json
+import os
+import zlib
+
+import pytest
+
+import modern_rzip_amd as m
+from tests import _parity, _util
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "vectors.json")) as f:
+    GOLD = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return _util.golden_inputs()
+
+
+def test_native_library_is_loaded(gpu_lib):
+    import torch
+    assert torch.cuda.is_available()
+    assert gpu_lib.mrz_abi_version() == 1
+    assert os.path.basename(m.lib_path()) == "libmrzgpu.so"
+    with open("/proc/self/maps") as f:
+        assert "libmrzgpu.so" in f.read()
+
+
+@pytest.mark.parametrize("name", list(GOLD["files"].keys()))
+def test_reference_golden_vectors(gpu_lib, oracle, inputs, name):
+    """Whole `mrzip -n -L7` output == the reference's."""
+    g = GOLD["files"][name]
+    got, st, md5 = m.rzip_buffer(inputs[name], level=7, lib=gpu_lib)
+    assert len(got) == g["mrz_len"]
+    assert hashlib.sha256(got).hexdigest() == g["sha256"]
+    for k, v in g["stats"].items():
+        assert getattr(st, k) == v, k
+    rc, back = oracle.decompress(got)
+    assert rc == 0 and back == inputs[name]
+
+
+@pytest.mark.parametrize("n", [0, 1, 30, 31, 32, 33, 63, 64, 65, 4095, 4096, 4097, 65535, 65536, 65537, 100003])
+def test_ragged_sizes(gpu_lib, oracle, n):
+    _parity.check_chunk(gpu_lib, oracle, (_util.zipf_text(max(n, 1), seed=n + 1) * 2)[:n])
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_levels_on_periodic_text(gpu_lib, oracle, level):
+    _parity.check_chunk(gpu_lib, oracle, _util.rep64k(40, seed=5), level=level)
+
+
+def test_syn64_chunk_state(gpu_lib, oracle, inputs):
+    want = _parity.check_chunk(gpu_lib, oracle, inputs["syn64"], table=True)
+    assert len(want["s0"]) == 23707 and len(want["s1"]) == 67521
+
+
+@pytest.mark.parametrize("vr", [0, 1, 7, 15])
+def test_victim_round_in_out(gpu_lib, oracle, vr):
+    _parity.check_chunk(gpu_lib, oracle, _util.rep64k(48, seed=9, period=4096), victim_round=vr)
+
+
+def test_text_with_culling(gpu_lib, oracle):
+    # 24 MB of Zipf text: the table passes its 2/3 limit, several cull sweeps complete
+    want = _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(12 << 20, seed=7), table=True)
+    assert want["min_mask"] > 1
+
+
+def test_noise_with_culling(gpu_lib, oracle):
+    want = _parity.check_chunk(gpu_lib, oracle, _util.xorshift_noise(8 << 20, seed=3))
+    assert want["min_mask"] > 1 and want["stats"]["matches"] == 0
+
+
+def test_tar_like_mix(gpu_lib, oracle):
+    _parity.check_chunk(gpu_lib, oracle, _util.tar_like(8 << 20, seed=5))
+
+
+def test_segment_boundaries(gpu_lib, oracle):
+    # > 16 Mi positions: the chunk spans two tag-scan segments, with matches crossing the seam
+    blk = _util.zipf_text(9 << 20, seed=31)
+    _parity.check_chunk(gpu_lib, oracle, blk + blk[: 8 << 20] + _util.xorshift_noise(1 << 20, seed=2))
+
+
+def test_long_match_pieces_and_backward(gpu_lib, oracle):
+    blk = _util.xorshift_noise(300000, seed=12)
+    _parity.check_chunk(gpu_lib, oracle, blk + blk + b"xyz" + blk[5:] + blk)
+
+
+def test_multi_chunk_file(gpu_lib, oracle):
+    data = _util.rep64k(96, seed=13)  # 6 MiB, chunks of 2 MiB+
+    _parity.check_file(gpu_lib, oracle, data, ramsize=3 * (2 << 20) // 2 + 5000)
+    _parity.check_file(gpu_lib, oracle, _util.tar_like(3 << 20, seed=8), level=9)
+
+
+def test_device_resident_input(gpu_lib, oracle):
+    import torch
+    data = _util.rep64k(64, seed=17)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    want = oracle.rzip_chunk(data)
+    with m.RzipContext(lib=gpu_lib, max_chunk=len(data)) as ctx:
+        res, s0, s1 = ctx.rzip_chunk(t)
+        assert (s0, s1, res.crc32) == (want["s0"], want["s1"], want["crc"])
+        # second chunk on the same ctx: table is reset, victim_round is chained
+        want2 = oracle.rzip_chunk(data, victim_round=want["victim_round"])
+        res2, s0b, s1b = ctx.rzip_chunk(t)
+        assert (s0b, s1b) == (want2["s0"], want2["s1"])
+        assert ctx.victim_round == want2["victim_round"]
+
+
+def test_crc32_kernel(gpu_lib):
+    with m.RzipContext(lib=gpu_lib) as ctx:
+        for n in (0, 1, 15, 17, 65535, 65536, 65537, 10 * 65536 + 77, (64 << 20) + 13):
+            d = _util.xorshift_noise(n, seed=n % 1000 + 5)
+            assert ctx.crc32(d) == zlib.crc32(d), n
+
+
+def test_large_property_roundtrip(gpu_lib, oracle):
+    """1 GiB S2-style stream (too long for the oracle's matcher in a test): the
+    archive must decode back to the input with matching CRC/MD5, and the stream
+    accounting must add up."""
+    import numpy as np
+    nper = 16384
+    data = _util.rep64k(nper, seed=1234)
+    with m.RzipContext(lib=gpu_lib, max_chunk=len(data)) as ctx:
+        res, s0, s1 = ctx.rzip_chunk(data)
+    assert res.crc32 == zlib.crc32(data)
+    st = res.stats
+    assert st.literal_bytes + st.match_bytes == len(data)
+    assert st.literal_bytes == len(s1)
+    md5 = hashlib.md5(data).digest()
+    mrz = oracle.frame(len(data), [(len(data), s0, s1)], md5)
+    rc, back = oracle.decompress(mrz)
+    assert rc == 0
+    assert hashlib.sha256(back).digest() == hashlib.sha256(data).digest()
+
+
+def test_blake2b_kernels(gpu_lib, oracle):
+    import torch
+    with m.RzipContext(lib=gpu_lib) as ctx:
+        msgs = [_util.xorshift_noise(n, seed=n + 1) for n in
+                (0, 1, 127, 128, 129, 256, 257, 1000, 65536, 1 << 20)] + [b"abc"] * 70
+        for outlen in (64, 32):
+            got = ctx.blake2b_batch(msgs, outlen)
+            assert got == [hashlib.blake2b(x, digest_size=outlen).digest() for x in msgs]
+        d = _util.xorshift_noise(223 * 999 + 40, seed=2)
+        rows = [d[i:i + 223 * 100] for i in range(0, len(d), 223 * 100)]
+        assert ctx.blake2b(d, pieces=rows) == hashlib.blake2b(d).digest() == oracle.blake2b(d)
+        t = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        assert ctx.blake2b(t) == hashlib.blake2b(d).digest()
+
+
+def test_lz4_sizes_and_gate(gpu_lib, oracle):
+    with open(os.path.join(HERE, "golden", "lz4_sizes.json")) as f:
+        gold = json.load(f)["sizes"]
+    from tests.golden import make_lz4_golden
+    cases = list(make_lz4_golden.cases())
+    with m.RzipContext(lib=gpu_lib) as ctx:
+        got = ctx.lz4_sizes([d for _, d in cases])
+        for (name, d), g in zip(cases, got):
+            assert g == gold[name], name
+        edge = [bytes(n) for n in (1, 12, 13, 14, 64)] + [_util.zipf_text(n, seed=n) for n in (13, 20, 100, 3000)]
+        assert ctx.lz4_sizes(edge) == [oracle.lz4_size(d) for d in edge]
+        blocks = [_util.zipf_text(3 << 20, seed=4), _util.xorshift_noise(3 << 20, seed=4), bytes(500000),
+                  _util.xorshift_noise(11 << 20, seed=5) + _util.zipf_text(2 << 20, seed=6),
+                  _util.tar_like(4 << 20, seed=3)]
+        for thr in (100, 60):
+            assert ctx.lz4_compresses(blocks, thr) == [oracle.lz4_compresses(b, thr) for b in blocks]
+
+
+def test_gate_on_gpu_preprocessed_streams(gpu_lib, oracle):
+    """cfg3 shape: GPU rzip -> LZ4 gate on both streams of the chunk."""
+    data = _util.tar_like(8 << 20, seed=21)
+    with m.RzipContext(lib=gpu_lib, max_chunk=len(data)) as ctx:
+        res, s0, s1 = ctx.rzip_chunk(data)
+        got = ctx.lz4_compresses([s0, s1], 100)
+    assert got == [oracle.lz4_compresses(s0, 100), oracle.lz4_compresses(s1, 100)]
