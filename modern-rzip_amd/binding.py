@@ -54,6 +54,13 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or lib_path()
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64, and whichever
+    # copy is loaded first must serve both (two runtimes in one process cannot both
+    # see the GPU).  Importing torch first makes libmrzgpu bind to torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise MrzError(f"{p} not found: build it with __graft_entry__.build() "
                        f"(make -C modern-rzip_amd/csrc); there is no CPU fallback")

@@ -98,8 +98,17 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     if (!out || level < 1 || level > 9 || max_chunk < 0) return MRZ_E_ARG;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MRZ_E_NODEVICE;
-    if (hipSetDevice(device) != hipSuccess) return MRZ_E_NODEVICE;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "libmrzgpu: hipGetDeviceCount -> %d (%s), %d device(s), asked for %d\n", (int)e0,
+                hipGetErrorString(e0), ndev, device);
+        return MRZ_E_NODEVICE;
+    }
+    e0 = hipSetDevice(device);
+    if (e0 != hipSuccess) {
+        fprintf(stderr, "libmrzgpu: hipSetDevice(%d) -> %d (%s)\n", device, (int)e0, hipGetErrorString(e0));
+        return MRZ_E_NODEVICE;
+    }
     mrz_ctx *ctx = (mrz_ctx *)calloc(1, sizeof(mrz_ctx));
     if (!ctx) return MRZ_E_NOMEM;
     ctx->device = device;
@@ -115,7 +124,11 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     mrz_make_hash_index(ctx->h_index);
 
     int rc = MRZ_OK;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) rc = MRZ_E_NODEVICE;
+    e0 = hipStreamCreate(&ctx->stream);
+    if (e0 != hipSuccess) {
+        fprintf(stderr, "libmrzgpu: hipStreamCreate -> %d (%s)\n", (int)e0, hipGetErrorString(e0));
+        rc = MRZ_E_NODEVICE;
+    }
     int64_t cap;
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_index, &cap, 256); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tab, &cap, ctx->nslots); }
@@ -318,7 +331,17 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     STEP(hipMemcpyAsync(&crc, ctx->d_crc_out, 4, hipMemcpyDeviceToHost, s));
     STEP(hipStreamSynchronize(s));
     if (herr == hipSuccess) {
-        if (hs.error || !hs.finished) rc = MRZ_E_OVERFLOW;
+        if (hs.error || !hs.finished) {
+            fprintf(stderr,
+                    "libmrzgpu: sequencer stopped abnormally: error=%d finished=%d p=%lld end=%lld events=%lld/%lld "
+                    "count=%lld min_mask=%lld\n",
+                    hs.error, hs.finished, (long long)hs.p, (long long)hs.end, (long long)hs.n_events,
+                    (long long)hs.event_cap, (long long)hs.count, (long long)hs.min_mask);
+            fprintf(stderr, "  dbg: n_events=%lld cap=%lld cur_len=%lld cur_p=%lld p=%lld mlen=%lld\n", (long long)hs.pad[0],
+                    (long long)hs.pad[1], (long long)hs.pad[2], (long long)hs.pad[3], (long long)hs.pad[4],
+                    (long long)hs.pad[5]);
+            rc = MRZ_E_OVERFLOW;
+        }
         E = hs.n_events;
     }
 

@@ -48,11 +48,22 @@ __device__ __forceinline__ int mrz_top_equal16(uint4 a, uint4 b) {
     return 16;
 }
 
-// wave-uniform broadcast of a 64-bit value held by lane `src`
+// The state machines in this library keep their control values wave-uniform.
+// Reading them back through v_readlane / v_readfirstlane tells the compiler so:
+// the values live in SGPRs and branches on them are scalar branches instead of
+// EXEC-masked vector code.
+__device__ __forceinline__ int mrz_lane_read(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int mrz_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t mrz_uni64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// wave-uniform broadcast of a 64-bit value held by lane `src` (src uniform)
 __device__ __forceinline__ int64_t mrz_bcast64(int64_t v, int src) {
-    int lo = __shfl((int)(uint32_t)(uint64_t)v, src, MRZ_WAVE);
-    int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, MRZ_WAVE);
-    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // mask with the low `k` bits set, k in [0, 64]

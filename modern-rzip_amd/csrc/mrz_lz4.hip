@@ -74,7 +74,7 @@ __device__ static int64_t mrz_lz_count(const uint8_t *src, int64_t a, int64_t b,
         const mrz_u64 stop = __ballot(!full);
         if (stop) {
             const int fl = __ffsll((long long)stop) - 1;
-            return base + (int64_t)fl * 16 + __shfl(lane_len, fl, MRZ_WAVE);
+            return base + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
         }
     }
 }
@@ -139,7 +139,7 @@ __device__ static int mrz_lz4_size_wave(const uint8_t *__restrict__ src, int n, 
             if (lane <= last_run && next_same > last_run) tab[h] = (uint32_t)pos;
             if (first_hit < first_end) {
                 ip = mrz_bcast64(pos, first_hit);
-                match = (int64_t)(uint32_t)__shfl((int)mi, first_hit, MRZ_WAVE);
+                match = (int64_t)(uint32_t)mrz_lane_read((int)mi, first_hit);
                 found = true;
                 break;
             }
@@ -201,7 +201,7 @@ __device__ static int mrz_lz4_size_wave(const uint8_t *__restrict__ src, int n, 
                 mi = tab[h];
                 tab[h] = (uint32_t)ip;
             }
-            mi = (uint32_t)__shfl((int)mi, 0, MRZ_WAVE);
+            mi = (uint32_t)mrz_lane_read((int)mi, 0);
             if ((small || (int64_t)mi + MRZ_LZ_MAXDIST >= ip) && mrz_ld4(src + mi) == mrz_ld4(src + ip)) {
                 op += 1;  // token of a zero-literal sequence
                 match = mi;

@@ -77,7 +77,7 @@ __device__ static int64_t mrz_wave_match_len(const uint8_t *__restrict__ buf, in
                 const mrz_u64 stop = __ballot(!full);
                 if (stop) {
                     const int fl = __ffsll((long long)stop) - 1;
-                    fwd = base + j * 1024 + (int64_t)fl * 16 + __shfl(lane_len, fl, MRZ_WAVE);
+                    fwd = base + j * 1024 + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
                     done = true;
                 }
             }
@@ -112,7 +112,7 @@ __device__ static int64_t mrz_wave_match_len(const uint8_t *__restrict__ buf, in
             const mrz_u64 stop = __ballot(!full);
             if (stop) {
                 const int fl = __ffsll((long long)stop) - 1;
-                rev = base + (int64_t)fl * 16 + __shfl(lane_len, fl, MRZ_WAVE);
+                rev = base + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
                 break;
             }
         }
@@ -202,7 +202,6 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     int64_t n_events = st->n_events;
     const int64_t event_cap = st->event_cap;
     int64_t inserts = st->inserts, tag_hits = st->tag_hits, tag_misses = st->tag_misses;
-    int error = 0, finished = 0;
     (void)n;
 
     const int64_t seg_start = a.seg_start;
@@ -246,11 +245,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         if (q < 0 || q > lim) {
             // nothing left for this launch
             if (p < lim) p = lim;
-            if (p >= end) finished = 1;
             break;
         }
         p = q;
-        const int64_t t = a.tags[p - seg_start];
+        const int64_t t = mrz_uni64(a.tags[p - seg_start]);
         if ((t & min_mask) != min_mask) continue;  // src/rzip.c:573 with the mask reached by now
 
         // ---- find_best_match (:426-462) -----------------------------------
@@ -297,8 +295,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                     int64_t occ_t = 0, occ_off = 0;
                     const int64_t hs = mrz_wave_insert_walk(tab, it, slot_mask, better, max_chain, &count,
                                                             &victim_round, &displace, &occ_t, &occ_off, lane);
-                    if (np >= MRZ_CASCADE_MAX) {
-                        error = 2;
+                    if (np >= MRZ_CASCADE_MAX) {  // cannot happen: every level has a strictly lower rank
+                        if (lane == 0) st->error = 2;
+                        np = 0;
                         break;
                     }
                     if (lane == 0) {
@@ -368,8 +367,8 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             cur_ofs = m_off;
         }
         if ((cur_len >= MRZ_GREAT_MATCH || p >= cur_p + MRZ_MIN_MATCH) && cur_len >= MRZ_MIN_MATCH) {
-            if (n_events >= event_cap) {
-                error = 1;
+            if (n_events >= event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
+                if (lane == 0) st->error = 1;
                 break;
             }
             if (lane == 0) {
@@ -384,7 +383,6 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             cur_p = p = last_match;
             cur_len = 0;
         }
-        if (error) break;
     }
 
     if (lane == 0) {
@@ -402,8 +400,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         st->inserts = inserts;
         st->tag_hits = tag_hits;
         st->tag_misses = tag_misses;
-        st->finished = finished;
-        st->error = error;
+        st->finished = p >= end ? 1 : 0;
     }
 }
 

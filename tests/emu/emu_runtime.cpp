@@ -9,6 +9,7 @@ namespace emu {
 
 struct WaveSync {
     int alive = 0, arrived = 0;
+    unsigned long long live_mask = 0;
     uint64_t phase = 0;
     int64_t slot[2][64];
     unsigned long long bal[2] = { 0, 0 };
@@ -82,6 +83,8 @@ int shfl_xor(int v, int mask) {
     return (int)(uint32_t)w->slot[par][src];
 }
 
+int first_live_lane() { return __builtin_ffsll((long long)cur->wave->live_mask) - 1; }
+
 void syncthreads() {
     if (++blk.arrived >= blk.alive) {
         blk.arrived = 0;
@@ -99,6 +102,7 @@ static void fiber_main() {
     // a finished thread no longer takes part in rendezvous
     WaveSync *w = me->wave;
     w->alive--;
+    w->live_mask &= ~(1ull << me->lane);
     if (w->alive > 0 && w->arrived >= w->alive) w->complete();
     blk.alive--;
     if (blk.alive > 0 && blk.arrived >= blk.alive) {
@@ -132,6 +136,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                     waves[wv] = WaveSync();
                     unsigned lanes = nthreads - wv * 64;
                     waves[wv].alive = lanes > 64 ? 64 : (int)lanes;
+                    waves[wv].live_mask = waves[wv].alive == 64 ? ~0ull : ((1ull << waves[wv].alive) - 1);
                     memset(waves[wv].slot, 0, sizeof(waves[wv].slot));
                 }
                 for (unsigned t = 0; t < nthreads; t++) {

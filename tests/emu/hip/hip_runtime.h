@@ -51,6 +51,7 @@ unsigned long long ballot(int pred);
 int shfl(int v, int src);
 int shfl_xor(int v, int mask);
 void syncthreads();
+int first_live_lane();
 }  // namespace emu
 
 #define threadIdx (emu::cur_tid)
@@ -65,6 +66,8 @@ static inline void __syncthreads() { emu::syncthreads(); }
 static inline unsigned long long __ballot(int pred) { return emu::ballot(pred); }
 static inline int __shfl(int v, int src, int width = 64) { (void)width; return emu::shfl(v, src); }
 static inline int __shfl_xor(int v, int m, int width = 64) { (void)width; return emu::shfl_xor(v, m); }
+static inline int __builtin_amdgcn_readlane(int v, int src) { return emu::shfl(v, src); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::shfl(v, emu::first_live_lane()); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
