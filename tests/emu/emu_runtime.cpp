@@ -83,6 +83,13 @@ int shfl_xor(int v, int mask) {
     return (int)(uint32_t)w->slot[par][src];
 }
 
+// a spin-wait's sleep: let the other fibers run
+void yield() {
+    Fiber *me = cur;
+    me->wait_ptr = nullptr;
+    swapcontext(&me->ctx, &sched_ctx);
+}
+
 int first_live_lane() { return __builtin_ffsll((long long)cur->wave->live_mask) - 1; }
 
 void syncthreads() {

@@ -52,6 +52,7 @@ int shfl(int v, int src);
 int shfl_xor(int v, int mask);
 void syncthreads();
 int first_live_lane();
+void yield();
 }  // namespace emu
 
 #define threadIdx (emu::cur_tid)
@@ -68,6 +69,12 @@ static inline int __shfl(int v, int src, int width = 64) { (void)width; return e
 static inline int __shfl_xor(int v, int m, int width = 64) { (void)width; return emu::shfl_xor(v, m); }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return emu::shfl(v, src); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::shfl(v, emu::first_live_lane()); }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+template <typename T> static inline T __hip_atomic_load(T *p, int, int) { return *(volatile T *)p; }
+template <typename T> static inline void __hip_atomic_store(T *p, T v, int, int) { *(volatile T *)p = v; }
+template <typename T> static inline T __hip_atomic_fetch_add(T *p, T v, int, int) { T o = *p; *p = o + v; return o; }
+static inline void __builtin_amdgcn_s_sleep(int) { emu::yield(); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
