@@ -22,12 +22,15 @@
 //     * cascades of displaced occupants are collected and written back
 //       innermost-first exactly like the reference's recursion;
 //     * clean_one_from_hash (:305-328): 64 slots per sweep step.
-//   waves 1..W-1 ("helpers") wait on an LDS mailbox.  When a look-up finds
-//   tag-equal entries the leader posts their offsets and every wave (leader
-//   included) runs single_match_len (:372-397) for one candidate: 64 lanes x
-//   16 B x 8 pieces per step forwards (ballot + ffs for the first mismatch),
-//   64 x 16 B backwards.  Results come back through LDS and are folded in
-//   probe order, so ties resolve exactly as in the reference.
+//     * single_match_len (:372-397), short path: up to 8 tag-equal entries at
+//       once, 8 lanes x 16 B each, forwards and backwards in ONE load round trip
+//       (most candidates differ within 128 bytes);
+//   waves 1..W-1 ("helpers") wait on an LDS mailbox.  A candidate that runs
+//   past 128 bytes takes the long path: its forward extension is striped over
+//   all W waves (W x 4 KiB per round, every wave 64 lanes x 16 B x 4 pieces,
+//   ballot + ffs for the first mismatch) and the leader folds the per-wave
+//   results.  Candidates are folded in probe order, so ties resolve exactly as
+//   in the reference.
 // Emitted matches go to an event list; record encoding, literal gathering and
 // the CRC are separate parallel kernels.
 //
@@ -40,9 +43,25 @@
 #define MRZ_SEQ_WAVES 16
 #endif
 #define MRZ_SEQ_THREADS (64 * MRZ_SEQ_WAVES)
-#define MRZ_FWD_UNROLL 8
 #define MRZ_CASCADE_MAX 64
-#define MRZ_MAX_JOBS 64
+
+// optional in-kernel cycle accounting (diagnostic builds only: -DMRZ_SEQ_PROFILE)
+#ifdef MRZ_SEQ_PROFILE
+#define PROF_DECL int64_t prof_t0 = 0, prof_acc[16] = { 0 }
+#define PROF_START() prof_t0 = (int64_t)__builtin_amdgcn_s_memtime()
+#define PROF_STOP(k)                                                     \
+    do {                                                                 \
+        const int64_t now__ = (int64_t)__builtin_amdgcn_s_memtime();     \
+        prof_acc[k] += now__ - prof_t0;                                  \
+        prof_t0 = now__;                                                 \
+    } while (0)
+#define PROF_COUNT(k) prof_acc[k] += 1
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_STOP(k)
+#define PROF_COUNT(k)
+#endif
 
 struct mrz_seq_args {
     const uint8_t *buf;
@@ -55,16 +74,15 @@ struct mrz_seq_args {
     int64_t seg_len;
 };
 
-// LDS mailbox between the leader and the helper waves
+// LDS mailbox between the leader and the helper waves: one long forward
+// extension at a time, striped over all waves of the workgroup
 struct mrz_mailbox {
-    int64_t p0, end, last_match;    // common to all jobs of a round
-    int64_t op[MRZ_MAX_JOBS];       // candidate offsets (probe order)
-    int64_t len[MRZ_MAX_JOBS];      // results
-    int64_t rev[MRZ_MAX_JOBS];
-    int njobs;
+    int64_t p0, op, maxf, base;     // compare buf[p0+x] with buf[op+x] for x in [base + wave*STRIPE, +STRIPE), x < maxf
+    int64_t res[MRZ_SEQ_WAVES];     // per wave: first stop offset of its stripe, or -1
     int seq;                        // bumped by the leader for every round; helpers wait on it
-    int done;                       // helpers add the number of jobs they finished
+    int done;                       // helpers add 1 when their stripe is finished
     int quit;
+    int pad;
 };
 
 // workgroup-scope accesses to the mailbox words
@@ -78,106 +96,184 @@ __device__ __forceinline__ void mrz_mb_add(int *p, int v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// ---- single_match_len (src/rzip.c:372-397), one wave per candidate ----------
-__device__ static int64_t mrz_wave_match_len(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, int64_t end,
-                                             int64_t last_match, int64_t *rev_out, int lane) {
+#define MRZ_STRIPE_PIECES 4
+#define MRZ_STRIPE (MRZ_STRIPE_PIECES * 1024)
+
+// Forward compare of one 4 KiB stripe starting at `base` (64 lanes x 16 B x 4
+// pieces, all loads issued before the first compare).  Returns the offset (from
+// p0) at which `while (p < end && buf[p] == buf[op])` (src/rzip.c:378) stops if
+// that lies inside or before this stripe's reach, else -1.
+__device__ static int64_t mrz_wave_fwd_stripe(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, int64_t maxf,
+                                              int64_t base, int lane) {
+    uint4 a[MRZ_STRIPE_PIECES], b[MRZ_STRIPE_PIECES];
+#pragma unroll
+    for (int j = 0; j < MRZ_STRIPE_PIECES; j++) {
+        const int64_t off = base + j * 1024 + lane * 16;
+        if (off < maxf) {
+            a[j] = mrz_ld16(buf + p0 + off);
+            b[j] = mrz_ld16(buf + op + off);
+        }
+    }
+    int64_t found = -1;
+#pragma unroll
+    for (int j = 0; j < MRZ_STRIPE_PIECES; j++) {
+        if (found >= 0) continue;
+        const int64_t off = base + j * 1024 + lane * 16;
+        int lane_len = 0;
+        bool full = false;
+        if (off < maxf) {
+            const int64_t rem = maxf - off;
+            const int lim = rem < 16 ? (int)rem : 16;
+            const int d = mrz_first_diff16(a[j], b[j]);
+            lane_len = d < lim ? d : lim;
+            full = lane_len == 16;
+        }
+        const mrz_u64 stop = __ballot(!full);
+        if (stop) {
+            const int fl = __ffsll((long long)stop) - 1;
+            found = base + j * 1024 + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
+        }
+    }
+    return found;
+}
+
+// Backward half of single_match_len (src/rzip.c:386-391), wave-wide.
+__device__ static int64_t mrz_wave_bwd(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, int64_t maxb,
+                                       int lane) {
+    if (maxb <= 0) return 0;
+    for (int64_t base = 0;; base += 1024) {
+        const int64_t off = base + lane * 16;
+        int lane_len = 0;
+        bool full = false;
+        if (off < maxb) {
+            const int64_t rem = maxb - off;
+            const int lim = rem < 16 ? (int)rem : 16;
+            int cnt;
+            if (op - off - 16 >= 0) {
+                cnt = mrz_top_equal16(mrz_ld16(buf + p0 - off - 16), mrz_ld16(buf + op - off - 16));
+            } else {
+                cnt = 0;
+                while (cnt < lim && buf[p0 - off - 1 - cnt] == buf[op - off - 1 - cnt]) cnt++;
+            }
+            lane_len = cnt < lim ? cnt : lim;
+            full = lane_len == 16;
+        }
+        const mrz_u64 stop = __ballot(!full);
+        if (stop) {
+            const int fl = __ffsll((long long)stop) - 1;
+            return base + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
+        }
+    }
+}
+
+// Long candidate: the forward extension is striped over every wave of the
+// workgroup (W x 4 KiB per round); the leader folds the per-wave results.
+__device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int *mb_seq, int64_t p0,
+                                             int64_t op, int64_t end, int64_t last_match, int64_t *rev_out, int lane) {
     *rev_out = 0;
     if (op >= p0) return 0;
-    // forward: while (p < end && buf[p] == buf[op])
     const int64_t maxf = end - p0;
     int64_t fwd = 0;
     if (maxf > 0) {
-        // first step: one piece per lane (most candidates end within 1 KiB)
-        int64_t base = 0;
-        bool done = false;
-        {
-            const int64_t off = (int64_t)lane * 16;
-            int lane_len = 0;
-            bool full = false;
-            if (off < maxf) {
-                const int64_t rem = maxf - off;
-                const int lim = rem < 16 ? (int)rem : 16;
-                const int d = mrz_first_diff16(mrz_ld16(buf + p0 + off), mrz_ld16(buf + op + off));
-                lane_len = d < lim ? d : lim;
-                full = lane_len == 16;
-            }
-            const mrz_u64 stop = __ballot(!full);
-            if (stop) {
-                const int fl = __ffsll((long long)stop) - 1;
-                fwd = (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
-                done = true;
-            }
-            base = 1024;
-        }
-        while (!done) {
-            uint4 a[MRZ_FWD_UNROLL], b[MRZ_FWD_UNROLL];
-#pragma unroll
-            for (int j = 0; j < MRZ_FWD_UNROLL; j++) {
-                const int64_t off = base + j * 1024 + lane * 16;
-                if (off < maxf) {
-                    a[j] = mrz_ld16(buf + p0 + off);
-                    b[j] = mrz_ld16(buf + op + off);
+        for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * MRZ_STRIPE) {
+            if (MRZ_SEQ_WAVES > 1) {
+                if (lane == 0) {
+                    mb->p0 = p0;
+                    mb->op = op;
+                    mb->maxf = maxf;
+                    mb->base = base;
+                    mb->done = 0;
                 }
+                *mb_seq += 1;
+                if (lane == 0) mrz_mb_store(&mb->seq, *mb_seq);
             }
-#pragma unroll
-            for (int j = 0; j < MRZ_FWD_UNROLL; j++) {
-                if (done) continue;
-                const int64_t off = base + j * 1024 + lane * 16;
-                int lane_len = 0;
-                bool full = false;
-                if (off < maxf) {
-                    const int64_t rem = maxf - off;
-                    const int lim = rem < 16 ? (int)rem : 16;
-                    const int d = mrz_first_diff16(a[j], b[j]);
-                    lane_len = d < lim ? d : lim;
-                    full = lane_len == 16;
-                }
-                const mrz_u64 stop = __ballot(!full);
-                if (stop) {
-                    const int fl = __ffsll((long long)stop) - 1;
-                    fwd = base + j * 1024 + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
-                    done = true;
-                }
+            int64_t best = mrz_wave_fwd_stripe(buf, p0, op, maxf, base, lane);  // the leader's own stripe (wave 0)
+            if (MRZ_SEQ_WAVES > 1) {
+                while (mrz_uni(mrz_mb_load(&mb->done)) < MRZ_SEQ_WAVES - 1) __builtin_amdgcn_s_sleep(1);
+                for (int w = 1; w < MRZ_SEQ_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
             }
-            base += (int64_t)MRZ_FWD_UNROLL * 1024;
-        }
-    }
-    // backward: while (p > max(0,last_match) && op > 0 && buf[op-1] == buf[p-1])
-    const int64_t floor_p = last_match > 0 ? last_match : 0;
-    int64_t maxb = p0 - floor_p;
-    if (op < maxb) maxb = op;
-    int64_t rev = 0;
-    if (maxb > 0) {
-        for (int64_t base = 0;; base += 1024) {
-            const int64_t off = base + lane * 16;
-            int lane_len = 0;
-            bool full = false;
-            if (off < maxb) {
-                const int64_t rem = maxb - off;
-                const int lim = rem < 16 ? (int)rem : 16;
-                int cnt;
-                if (op - off - 16 >= 0) {
-                    const uint4 a = mrz_ld16(buf + p0 - off - 16);
-                    const uint4 b = mrz_ld16(buf + op - off - 16);
-                    cnt = mrz_top_equal16(a, b);
-                } else {
-                    cnt = 0;
-                    while (cnt < lim && buf[p0 - off - 1 - cnt] == buf[op - off - 1 - cnt]) cnt++;
-                }
-                lane_len = cnt < lim ? cnt : lim;
-                full = lane_len == 16;
-            }
-            const mrz_u64 stop = __ballot(!full);
-            if (stop) {
-                const int fl = __ffsll((long long)stop) - 1;
-                rev = base + (int64_t)fl * 16 + mrz_lane_read(lane_len, fl);
+            if (best >= 0) {
+                fwd = best;
                 break;
             }
         }
     }
+    const int64_t floor_p = last_match > 0 ? last_match : 0;
+    int64_t maxb = p0 - floor_p;
+    if (op < maxb) maxb = op;
+    const int64_t rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
     *rev_out = rev;
     const int64_t len = fwd + rev;
     return len < MRZ_MIN_MATCH ? 0 : len;
+}
+
+#define MRZ_SHORT_BYTES 128  // reach of the 8-lane short path, each direction
+
+// Short path: up to 8 tag-equal candidates at once, 8 lanes (128 B) each,
+// forwards and backwards in a single load round trip.  Per group (lane>>3):
+// *len / *rev as single_match_len would return them, or *is_long when either
+// direction ran through all 128 bytes (the caller then uses the striped path).
+__device__ static void mrz_short_match_len(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, bool valid,
+                                           int64_t end, int64_t last_match, int lane, int64_t *len, int64_t *rev,
+                                           bool *is_long) {
+    const int i = lane & 7;
+    const int g8 = lane & ~7;
+    const int64_t off = (int64_t)i * 16;
+    valid = valid && op < p0;
+    const int64_t maxf = end - p0;
+    int f_len = 0;
+    bool f_full = false;
+    uint4 fa, fb, ba, bb;
+    const bool f_act = valid && off < maxf;
+    if (f_act) {
+        fa = mrz_ld16(buf + p0 + off);
+        fb = mrz_ld16(buf + op + off);
+    }
+    const int64_t floor_p = last_match > 0 ? last_match : 0;
+    int64_t maxb = p0 - floor_p;
+    if (op < maxb) maxb = op;
+    const bool b_act = valid && off < maxb;
+    const bool b_wide = b_act && (op - off - 16 >= 0);
+    if (b_wide) {
+        ba = mrz_ld16(buf + p0 - off - 16);
+        bb = mrz_ld16(buf + op - off - 16);
+    }
+    if (f_act) {
+        const int64_t rem = maxf - off;
+        const int lim = rem < 16 ? (int)rem : 16;
+        const int d = mrz_first_diff16(fa, fb);
+        f_len = d < lim ? d : lim;
+        f_full = f_len == 16;
+    }
+    int b_len = 0;
+    bool b_full = false;
+    if (b_act) {
+        const int64_t rem = maxb - off;
+        const int lim = rem < 16 ? (int)rem : 16;
+        int cnt;
+        if (b_wide)
+            cnt = mrz_top_equal16(ba, bb);
+        else {
+            cnt = 0;
+            while (cnt < lim && buf[p0 - off - 1 - cnt] == buf[op - off - 1 - cnt]) cnt++;
+        }
+        b_len = cnt < lim ? cnt : lim;
+        b_full = b_len == 16;
+    }
+    const mrz_u64 f_stop = __ballot(!f_full);
+    const mrz_u64 b_stop = __ballot(!b_full);
+    const unsigned fbits = (unsigned)(f_stop >> g8) & 0xffu;
+    const unsigned bbits = (unsigned)(b_stop >> g8) & 0xffu;
+    const int ffi = fbits ? __ffs((int)fbits) - 1 : 0;
+    const int bfi = bbits ? __ffs((int)bbits) - 1 : 0;
+    const int f_at = __shfl(f_len, g8 + ffi, MRZ_WAVE);
+    const int b_at = __shfl(b_len, g8 + bfi, MRZ_WAVE);
+    const int64_t fwd = ffi * 16 + f_at;
+    const int64_t rv = bfi * 16 + b_at;
+    *is_long = valid && (fbits == 0 || bbits == 0);
+    *rev = valid ? rv : 0;
+    const int64_t l = fwd + rv;
+    *len = (valid && l >= MRZ_MIN_MATCH) ? l : 0;
 }
 
 // One 64-slot step of insert_hash's probe walk (src/rzip.c:264-297) over the
@@ -231,7 +327,7 @@ __device__ __forceinline__ bool mrz_insert_step(const mrz_slot e, bool empty, in
     return false;
 }
 
-// helper waves: serve match-extension rounds until the leader says quit
+// helper waves: serve striped forward-extension rounds until the leader says quit
 __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int wave, int lane) {
     int seen = 0;
     while (true) {
@@ -239,19 +335,13 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
         while ((s = mrz_uni(mrz_mb_load(&mb->seq))) == seen) __builtin_amdgcn_s_sleep(2);
         seen = s;
         if (mrz_uni(mrz_mb_load(&mb->quit))) return;
-        const int nj = mrz_uni(mb->njobs);
-        const int64_t p0 = mrz_uni64(mb->p0), end = mrz_uni64(mb->end), lm = mrz_uni64(mb->last_match);
-        int mine = 0;
-        for (int j = wave; j < nj; j += MRZ_SEQ_WAVES) {
-            int64_t rev = 0;
-            const int64_t ml = mrz_wave_match_len(buf, p0, mrz_uni64(mb->op[j]), end, lm, &rev, lane);
-            if (lane == 0) {
-                mb->len[j] = ml;
-                mb->rev[j] = rev;
-            }
-            mine++;
+        const int64_t p0 = mrz_uni64(mb->p0), op = mrz_uni64(mb->op), maxf = mrz_uni64(mb->maxf);
+        const int64_t base = mrz_uni64(mb->base) + (int64_t)wave * MRZ_STRIPE;
+        const int64_t r = mrz_wave_fwd_stripe(buf, p0, op, maxf, base, lane);
+        if (lane == 0) {
+            mb->res[wave] = r;
+            mrz_mb_add(&mb->done, 1);
         }
-        if (mine && lane == 0) mrz_mb_add(&mb->done, mine);
     }
 }
 
@@ -268,7 +358,6 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 
     if (st->finished || st->error) return;
     if (threadIdx.x == 0) {
-        mb->njobs = 0;
         mb->seq = 0;
         mb->done = 0;
         mb->quit = 0;
@@ -303,8 +392,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     int64_t win_base = -1;
     mrz_u64 myword = 0;
     int mb_seq = 0;
+    PROF_DECL;
 
     while (true) {
+        PROF_START();
         // ---- next position > p whose bitmap bit is set -------------------
         int64_t q = -1;
         {
@@ -340,7 +431,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             break;
         }
         p = q;
+        PROF_STOP(0);  // candidate discovery
         const int64_t t = mrz_uni64(a.tags[p - seg_start]);
+        PROF_STOP(1);  // tag fetch
+        PROF_COUNT(8);
         if ((t & min_mask) != min_mask) continue;  // src/rzip.c:573 with the mask reached by now
 
         // ---- one pass over the chain: find_best_match (:426-462) and, when this
@@ -364,56 +458,57 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 const mrz_slot e = tab[s];
                 const bool empty = (e.off | e.t) == 0;
                 const mrz_u64 m_empty = __ballot(empty);
+                PROF_STOP(2);  // chain load
                 const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : MRZ_WAVE;
                 if (!ins_found)
                     ins_found = mrz_insert_step(e, empty, t, my_rank, h0 + b, slot_mask, better, max_chain, &round,
                                                 &victim_h, &count, &victim_round, &ins_slot, &ins_kind, &occ_t,
                                                 &occ_off);
                 const mrz_u64 m_same = __ballot(!empty && e.t == t) & mrz_low_mask(first_empty);
+                PROF_STOP(3);  // classify
+                PROF_COUNT(9);
                 if (m_same) {
-                    // post the tag-equal entries of this step, probe order
-                    const int nj = __popcll(m_same);
-                    const int my_idx = __popcll(m_same & mrz_low_mask(lane));
-                    if ((m_same >> lane) & 1) mb->op[my_idx] = e.off;
-                    if (lane == 0) {
-                        mb->p0 = p;
-                        mb->end = end;
-                        mb->last_match = last_match;
-                        mb->njobs = nj;
-                        mb->done = 0;
-                    }
-                    // jobs 0, W, 2W, .. stay with the leader
-                    const int leader_jobs = (nj + MRZ_SEQ_WAVES - 1) / MRZ_SEQ_WAVES;
-                    const int helper_jobs = nj - leader_jobs;
-                    if (helper_jobs) {
-                        mb_seq++;
-                        if (lane == 0) mrz_mb_store(&mb->seq, mb_seq);
-                    }
-                    for (int j = 0; j < nj; j += MRZ_SEQ_WAVES) {
-                        int64_t rev = 0;
-                        const int64_t op = mrz_uni64(mb->op[j]);
-                        const int64_t ml = mrz_wave_match_len(buf, p, op, end, last_match, &rev, lane);
-                        if (lane == 0) {
-                            mb->len[j] = ml;
-                            mb->rev[j] = rev;
+                    PROF_COUNT(10);
+                    // tag-equal entries of this step, probe order, 8 per pass
+                    mrz_u64 todo = m_same;
+                    while (todo) {
+                        // the g-th remaining entry goes to lane group g
+                        const int g = lane >> 3;
+                        mrz_u64 tmp = todo;
+                        int src_lane = -1, npass = 0;
+                        for (int k = 0; k < 8 && tmp; k++) {
+                            const int sl = __ffsll((long long)tmp) - 1;
+                            tmp &= tmp - 1;
+                            if (k == g) src_lane = sl;
+                            npass++;
                         }
+                        const bool valid = src_lane >= 0;
+                        const int rd = valid ? src_lane : 0;
+                        const int lo = __shfl((int)(uint32_t)(uint64_t)e.off, rd, MRZ_WAVE);
+                        const int hi = __shfl((int)(uint32_t)((uint64_t)e.off >> 32), rd, MRZ_WAVE);
+                        const int64_t op = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+                        int64_t g_len, g_rev;
+                        bool g_long;
+                        mrz_short_match_len(buf, p, op, valid, end, last_match, lane, &g_len, &g_rev, &g_long);
+                        for (int k = 0; k < npass; k++) {
+                            int64_t ml = mrz_bcast64(g_len, 8 * k);
+                            int64_t rv = mrz_bcast64(g_rev, 8 * k);
+                            const int64_t opk = mrz_bcast64(op, 8 * k);
+                            if (mrz_lane_read(g_long ? 1 : 0, 8 * k))
+                                ml = mrz_long_match_len(buf, mb, &mb_seq, p, opk, end, last_match, &rv, lane);
+                            if (ml) {  // first longest wins, :446-450
+                                if (ml > mlen) {
+                                    mlen = ml;
+                                    m_off = opk - rv;
+                                    m_rev = rv;
+                                }
+                                tag_hits++;
+                            } else
+                                tag_misses++;
+                        }
+                        todo = tmp;
                     }
-                    if (helper_jobs)
-                        while (mrz_uni(mrz_mb_load(&mb->done)) < helper_jobs) __builtin_amdgcn_s_sleep(1);
-                    // fold in probe order (first longest wins, :446-450)
-                    for (int j = 0; j < nj; j++) {
-                        const int64_t ml = mrz_uni64(mb->len[j]);
-                        if (ml) {
-                            if (ml > mlen) {
-                                const int64_t rv = mrz_uni64(mb->rev[j]);
-                                mlen = ml;
-                                m_off = mrz_uni64(mb->op[j]) - rv;
-                                m_rev = rv;
-                            }
-                            tag_hits++;
-                        } else
-                            tag_misses++;
-                    }
+                    PROF_STOP(4);  // match jobs
                 }
                 if (first_empty < MRZ_WAVE) break;
             }
@@ -461,6 +556,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                     tab[hs] = w;
                 }
             }
+            PROF_STOP(5);  // insert write-back / cascades
             if (count > limit) {
                 // clean_one_from_hash (:305-328)
                 while (true) {
@@ -499,6 +595,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             }
         }
 
+        PROF_STOP(6);  // cull
         // ---- lazy selection + emission (:586-599) -------------------------
         if (mlen > cur_len) {
             cur_p = p - m_rev;
@@ -522,6 +619,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             cur_p = p = last_match;
             cur_len = 0;
         }
+        PROF_STOP(7);  // select / emit
     }
 
     // release the helpers, then publish the state for the next segment's launch
@@ -543,6 +641,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         st->tag_hits = tag_hits;
         st->tag_misses = tag_misses;
         st->finished = p >= end ? 1 : 0;
+#ifdef MRZ_SEQ_PROFILE
+        for (int k = 0; k < 16; k++) st->prof[k] += prof_acc[k];
+#endif
     }
 }
 
