@@ -77,3 +77,54 @@ __device__ __forceinline__ int mrz_nth_set(mrz_u64 m, int k) {
 
 // trailing-ones rank used by lesser_bitness (src/rzip.c:248-252): ffsll(~t)
 __device__ __forceinline__ int mrz_ones_rank(int64_t t) { return __ffsll((long long)~t); }
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int mrz_wave_incl_sum(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl(v, lane - d >= 0 ? lane - d : lane, MRZ_WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// position of the k-th (0-based) set bit of w; w must have more than k bits set
+__device__ __forceinline__ int mrz_select64(mrz_u64 w, int k) {
+    int pos = 0;
+    uint32_t x = (uint32_t)w;
+    int c = __popc(x);
+    if (k >= c) {
+        k -= c;
+        pos = 32;
+        x = (uint32_t)(w >> 32);
+    }
+    c = __popc(x & 0xffffu);
+    if (k >= c) {
+        k -= c;
+        pos += 16;
+        x >>= 16;
+    }
+    x &= 0xffffu;
+    c = __popc(x & 0xffu);
+    if (k >= c) {
+        k -= c;
+        pos += 8;
+        x >>= 8;
+    }
+    x &= 0xffu;
+    c = __popc(x & 0xfu);
+    if (k >= c) {
+        k -= c;
+        pos += 4;
+        x >>= 4;
+    }
+    x &= 0xfu;
+    c = __popc(x & 3u);
+    if (k >= c) {
+        k -= c;
+        pos += 2;
+        x >>= 2;
+    }
+    x &= 3u;
+    return pos + (k >= (int)(x & 1u) ? 1 : 0);
+}

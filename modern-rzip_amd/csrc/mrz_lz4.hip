@@ -40,16 +40,6 @@ __device__ __forceinline__ uint32_t mrz_lz_hash(const uint8_t *p, bool small) {
     return (uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 12));
 }
 
-// inclusive prefix sum over the wave
-__device__ __forceinline__ int mrz_wave_incl_sum(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl(v, lane - d >= 0 ? lane - d : lane, MRZ_WAVE);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
-
 // number of equal bytes of a[0..) and b[0..) with a limited to [.., alimit)
 __device__ static int64_t mrz_lz_count(const uint8_t *src, int64_t a, int64_t b, int64_t alimit, int lane) {
     const int64_t maxf = alimit - a;

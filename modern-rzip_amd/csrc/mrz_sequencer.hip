@@ -345,14 +345,720 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
     }
 }
 
+// ---- leader state ----------------------------------------------------------------
+struct mrz_lead {  // wave-uniform; what hash_search keeps in locals / rzip_state
+    int64_t p, cur_p, cur_ofs, cur_len, last_match;
+    int64_t min_mask, tag_mask, count, clean_ptr, victim_round;
+    int64_t n_events, inserts, tag_hits, tag_misses;
+};
+
+struct mrz_cfg {
+    const uint8_t *buf;
+    mrz_slot *tab;
+    mrz_event *events;
+    mrz_seq_state *st;
+    int64_t end, limit, max_chain, slot_mask, nslots, event_cap;
+};
+
+// lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
+// look-up returned (mlen, m_off, m_rev).  Returns false on event-list overflow.
+__device__ __forceinline__ bool mrz_select_emit(const mrz_cfg &C, mrz_lead &L, int64_t mlen, int64_t m_off,
+                                                int64_t m_rev, int lane) {
+    if (mlen > L.cur_len) {
+        L.cur_p = L.p - m_rev;
+        L.cur_len = mlen;
+        L.cur_ofs = m_off;
+    }
+    if ((L.cur_len >= MRZ_GREAT_MATCH || L.p >= L.cur_p + MRZ_MIN_MATCH) && L.cur_len >= MRZ_MIN_MATCH) {
+        if (L.n_events >= C.event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
+            if (lane == 0) C.st->error = 1;
+            return false;
+        }
+        if (lane == 0) {
+            mrz_event ev;
+            ev.p = L.cur_p;
+            ev.ofs = L.cur_ofs;
+            ev.len = L.cur_len;
+            C.events[L.n_events] = ev;
+        }
+        L.n_events++;
+        L.last_match = L.cur_p + L.cur_len;
+        L.cur_p = L.p = L.last_match;
+        L.cur_len = 0;
+    }
+    return true;
+}
+
+// clean_one_from_hash (src/rzip.c:305-328), 64 slots per sweep step
+__device__ static void mrz_cull_one(const mrz_cfg &C, mrz_lead &L, int lane) {
+    mrz_slot *tab = C.tab;
+    while (true) {
+        const int64_t better2 = (L.min_mask << 1) | 1;
+        bool culled = false;
+        while (L.clean_ptr < C.nslots) {
+            const int64_t s = L.clean_ptr + lane;
+            mrz_slot e;
+            e.off = 0;
+            e.t = 0;
+            if (s < C.nslots) e = tab[s];
+            const bool hit = ((e.off | e.t) != 0) && ((e.t & better2) != better2);
+            const mrz_u64 m = __ballot(hit);
+            if (m) {
+                const int fl = __ffsll((long long)m) - 1;
+                L.clean_ptr += fl;
+                if (lane == fl) {
+                    mrz_slot z;
+                    z.off = 0;
+                    z.t = 0;
+                    tab[s] = z;
+                }
+                L.count--;
+                culled = true;
+                break;
+            }
+            L.clean_ptr += MRZ_WAVE;
+        }
+        if (culled) {
+            L.tag_mask = better2;
+            return;
+        }
+        L.min_mask = better2;
+        L.clean_ptr = 0;
+    }
+}
+
+// One candidate, fully in order: the wave-cooperative path (any chain length,
+// any match length, cascades, chain-limit evictions, mask promotion).
+__device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_mailbox *mb, int *mb_seq, int64_t *pend_h,
+                                         int64_t *pend_t, int64_t *pend_o, int64_t t, int lane) {
+    const uint8_t *__restrict__ buf = C.buf;
+    mrz_slot *tab = C.tab;
+    const int64_t p = L.p, end = C.end, slot_mask = C.slot_mask, max_chain = C.max_chain;
+    // ---- one pass over the chain: find_best_match (:426-462) and, when this
+    // position is inserted (:579), the probe walk of insert_hash ----------
+    const bool do_insert = (t & L.tag_mask) == L.tag_mask;
+    const int64_t better = (L.min_mask << 1) | 1;
+    const int my_rank = mrz_ones_rank(t);
+    int64_t mlen = 0, m_off = 0, m_rev = 0;
+    bool ins_found = !do_insert;
+    int64_t ins_slot = 0, occ_t = 0, occ_off = 0;
+    int ins_kind = 0;
+    if (do_insert) {
+        L.inserts++;
+        L.count++;
+    }
+    {
+        const int64_t h0 = t & slot_mask;
+        int64_t round = 0, victim_h = 0;
+        for (int64_t b = 0;; b += MRZ_WAVE) {
+            const int64_t s = (h0 + b + lane) & slot_mask;
+            const mrz_slot e = tab[s];
+            const bool empty = (e.off | e.t) == 0;
+            const mrz_u64 m_empty = __ballot(empty);
+            const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : MRZ_WAVE;
+            if (!ins_found)
+                ins_found = mrz_insert_step(e, empty, t, my_rank, h0 + b, slot_mask, better, max_chain, &round,
+                                            &victim_h, &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t,
+                                            &occ_off);
+            const mrz_u64 m_same = __ballot(!empty && e.t == t) & mrz_low_mask(first_empty);
+            if (m_same) {
+                // tag-equal entries of this step, probe order, 8 per pass
+                mrz_u64 todo = m_same;
+                while (todo) {
+                    const int g = lane >> 3;  // the g-th remaining entry goes to lane group g
+                    mrz_u64 tmp = todo;
+                    int src_lane = -1, npass = 0;
+                    for (int k = 0; k < 8 && tmp; k++) {
+                        const int sl = __ffsll((long long)tmp) - 1;
+                        tmp &= tmp - 1;
+                        if (k == g) src_lane = sl;
+                        npass++;
+                    }
+                    const bool valid = src_lane >= 0;
+                    const int rd = valid ? src_lane : 0;
+                    const int lo = __shfl((int)(uint32_t)(uint64_t)e.off, rd, MRZ_WAVE);
+                    const int hi = __shfl((int)(uint32_t)((uint64_t)e.off >> 32), rd, MRZ_WAVE);
+                    const int64_t op = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+                    int64_t g_len, g_rev;
+                    bool g_long;
+                    mrz_short_match_len(buf, p, op, valid, end, L.last_match, lane, &g_len, &g_rev, &g_long);
+                    for (int k = 0; k < npass; k++) {
+                        int64_t ml = mrz_bcast64(g_len, 8 * k);
+                        int64_t rv = mrz_bcast64(g_rev, 8 * k);
+                        const int64_t opk = mrz_bcast64(op, 8 * k);
+                        if (mrz_lane_read(g_long ? 1 : 0, 8 * k))
+                            ml = mrz_long_match_len(buf, mb, mb_seq, p, opk, end, L.last_match, &rv, lane);
+                        if (ml) {  // first longest wins, :446-450
+                            if (ml > mlen) {
+                                mlen = ml;
+                                m_off = opk - rv;
+                                m_rev = rv;
+                            }
+                            L.tag_hits++;
+                        } else
+                            L.tag_misses++;
+                    }
+                    todo = tmp;
+                }
+            }
+            if (first_empty < MRZ_WAVE) break;
+        }
+    }
+
+    // ---- insert + cull (:579-584) -------------------------------------
+    if (do_insert) {
+        int np = 0;
+        int64_t it = t, io = p;
+        while (true) {
+            if (np >= MRZ_CASCADE_MAX) {  // cannot happen: every level has a strictly lower rank
+                if (lane == 0) C.st->error = 2;
+                return false;
+            }
+            if (lane == 0) {
+                pend_h[np] = ins_slot;
+                pend_t[np] = it;
+                pend_o[np] = io;
+            }
+            np++;
+            if (ins_kind != 2) break;
+            // re-insert the displaced occupant: its own probe walk
+            it = occ_t;
+            io = occ_off;
+            const int64_t h0 = it & slot_mask;
+            const int rank2 = mrz_ones_rank(it);
+            int64_t round = 0, victim_h = 0;
+            for (int64_t b = 0;; b += MRZ_WAVE) {
+                const int64_t s = (h0 + b + lane) & slot_mask;
+                const mrz_slot e = tab[s];
+                const bool empty = (e.off | e.t) == 0;
+                if (mrz_insert_step(e, empty, it, rank2, h0 + b, slot_mask, better, max_chain, &round, &victim_h,
+                                    &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t, &occ_off))
+                    break;
+            }
+        }
+        // write back innermost-first (the recursion's return order)
+        while (np-- > 0) {
+            const int64_t hs = mrz_uni64(pend_h[np]);
+            if (lane == 0) {
+                mrz_slot w;
+                w.off = pend_o[np];
+                w.t = pend_t[np];
+                tab[hs] = w;
+            }
+        }
+        if (L.count > C.limit) mrz_cull_one(C, L, lane);
+    }
+    return mrz_select_emit(C, L, mlen, m_off, m_rev, lane);
+}
+
+// ---- the batch engine -------------------------------------------------------------
+// Up to 64 consecutive candidates are processed at once, ONE LANE PER CANDIDATE,
+// against the table as it stands at the start of the batch:
+//   1. every lane walks its own probe chain (4 slots = 64 B per step) and records
+//      first-empty, the tag-equal entries, and where insert_hash's walk stops
+//      (empty / due-for-culling overwrite / lower-ranked occupant to displace / the
+//      max_chain_len-th tag-equal entry => victim eviction);
+//   1b. lanes that displace an occupant walk that occupant's chain too;
+//   2. every lane extends its tag-equal candidates itself, 64 B each way;
+//   3. wave scans turn the per-lane facts into the sequential quantities:
+//      victim_round per evicting lane (prefix count), hash_count before each lane
+//      (saturating prefix sum), which lanes cull and which sweep entry each culls
+//      (rank into the ballot of failing entries ahead of tag_clean_ptr);
+//   4. a lane may only be committed if no EARLIER lane's write (insert, displaced
+//      re-insert, cull) falls inside the slots it read: an LDS filter keyed by
+//      64-slot block flags suspects, suspects are checked exactly.  The batch is
+//      cut at the first lane that conflicts or needs the cooperative path
+//      (long match, long chain, deep cascade, sweep wrap, mask transition), the
+//      lazy-match fold (:586-599) may cut it earlier at an emission;
+//   5. all surviving lanes write their slots in one go.
+// The committed prefix is exactly what the reference's loop would have done.
+#define MRZ_SMAX 16
+#define MRZ_WALK_STEPS 24
+#define MRZ_FILTER_SIZE 4096
+#define MRZ_CULL_WINDOW 4  // x 64 slots scanned ahead of tag_clean_ptr per batch
+
+struct mrz_batch_lds {
+    int pref[64];
+    mrz_u64 word[64];
+    int64_t same_off[64][MRZ_SMAX];
+    int same_slot[64][MRZ_SMAX];
+    unsigned filter[MRZ_FILTER_SIZE];
+};
+
+#ifdef __HIP_DEVICE_COMPILE__
+#define MRZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define MRZ_WAVE_SYNC() (void)__ballot(1)
+#endif
+
+__device__ __forceinline__ unsigned mrz_filter_slot(int slot) {
+    return ((unsigned)(slot >> 6) * 2654435761u) >> 20;  // 12 bits
+}
+
+// per-lane forward/backward extension of one candidate, 64 B reach each way
+__device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64_t q, int64_t op, int64_t end,
+                                          int64_t last_match, int64_t *len, int64_t *rev, bool *is_long) {
+    *len = 0;
+    *rev = 0;
+    *is_long = false;
+    if (op >= q) return;
+    const int64_t maxf = end - q;
+    int64_t fwd = 0;
+    bool lng = false;
+    if (maxf > 0) {
+        uint4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((int64_t)j * 16 < maxf) {
+                a[j] = mrz_ld16(buf + q + j * 16);
+                b[j] = mrz_ld16(buf + op + j * 16);
+            }
+        bool stop = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (stop) continue;
+            const int64_t off = (int64_t)j * 16;
+            if (off >= maxf) {
+                fwd = maxf;
+                stop = true;
+                continue;
+            }
+            const int64_t rem = maxf - off;
+            const int lim = rem < 16 ? (int)rem : 16;
+            const int d = mrz_first_diff16(a[j], b[j]);
+            const int ll = d < lim ? d : lim;
+            if (ll < 16) {
+                fwd = off + ll;
+                stop = true;
+            }
+        }
+        if (!stop) {
+            if (maxf <= 64)
+                fwd = maxf;
+            else
+                lng = true;
+        }
+    }
+    const int64_t floor_p = last_match > 0 ? last_match : 0;
+    int64_t maxb = q - floor_p;
+    if (op < maxb) maxb = op;
+    int64_t rv = 0;
+    if (maxb > 0 && !lng) {
+        bool stop = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (stop) continue;
+            const int64_t off = (int64_t)j * 16;
+            if (off >= maxb) {
+                rv = maxb;
+                stop = true;
+                continue;
+            }
+            const int64_t rem = maxb - off;
+            const int lim = rem < 16 ? (int)rem : 16;
+            int cnt;
+            if (op - off - 16 >= 0)
+                cnt = mrz_top_equal16(mrz_ld16(buf + q - off - 16), mrz_ld16(buf + op - off - 16));
+            else {
+                cnt = 0;
+                while (cnt < lim && buf[q - off - 1 - cnt] == buf[op - off - 1 - cnt]) cnt++;
+            }
+            const int ll = cnt < lim ? cnt : lim;
+            if (ll < 16) {
+                rv = off + ll;
+                stop = true;
+            }
+        }
+        if (!stop) {
+            if (maxb <= 64)
+                rv = maxb;
+            else
+                lng = true;
+        }
+    }
+    if (lng) {
+        *is_long = true;
+        return;
+    }
+    *rev = rv;
+    const int64_t l = fwd + rv;
+    *len = l >= MRZ_MIN_MATCH ? l : 0;
+}
+
+// Returns the number of candidates consumed from this window (>= 1), or 0 when the
+// first candidate has to go through mrz_seq_candidate.  `w` is this lane's bitmap
+// word of the 4096-position window starting at `wb`, already masked to (L.p, lim].
+__device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_lds *B, const int64_t *__restrict__ tags,
+                                     int64_t seg_start, int64_t wb, mrz_u64 w, unsigned epoch, int lane, bool *ok) {
+    const uint8_t *__restrict__ buf = C.buf;
+    mrz_slot *tab = C.tab;
+    const int smask = (int)C.slot_mask;
+    const int max_chain = (int)C.max_chain;
+    const int64_t better = (L.min_mask << 1) | 1;
+    *ok = true;
+
+    // ---- formation: lane r takes the r-th candidate of the window ------------
+    const int cnt = __popcll(w);
+    const int incl = mrz_wave_incl_sum(cnt, lane);
+    const int total = mrz_lane_read(incl, 63);
+    const int nb = total < 64 ? total : 64;
+    B->pref[lane] = incl - cnt;
+    B->word[lane] = w;
+    MRZ_WAVE_SYNC();
+    const bool have = lane < nb;
+    int wlo = 0, whi = 63;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int mid = (wlo + whi + 1) >> 1;
+        if (B->pref[mid] <= lane)
+            wlo = mid;
+        else
+            whi = mid - 1;
+    }
+    int64_t q = 0, t = 0;
+    if (have) {
+        q = wb + (int64_t)wlo * 64 + mrz_select64(B->word[wlo], lane - B->pref[wlo]);
+        t = tags[q - seg_start];
+    }
+    const bool act = have && (t & L.min_mask) == L.min_mask;
+    const bool do_ins = act && (t & L.tag_mask) == L.tag_mask;
+
+    // ---- phase 1: per-lane probe walk ------------------------------------------
+    const int h = (int)(t & C.slot_mask);
+    const int my_rank = mrz_ones_rank(t);
+    int fe = -1, wslot = -1, kind = -1;  // kind: 0 empty, 1 overwrite, 2 displace, 3 evict
+    int nsame = 0, round = 0;
+    bool cplx = false, evict = false;
+    int64_t occ_t = 0, occ_off = 0;
+    {
+        bool walking = act;
+        int s = h, steps = 0;
+        while (__ballot(walking)) {
+            if (walking) {
+                mrz_slot e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[k] = tab[(s + k) & smask];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (!walking) continue;
+                    const int slot = (s + k) & smask;
+                    if ((e[k].off | e[k].t) == 0) {
+                        fe = slot;
+                        if (do_ins && wslot < 0 && !evict) {
+                            wslot = slot;
+                            kind = 0;
+                        }
+                        walking = false;
+                        continue;
+                    }
+                    if (do_ins && wslot < 0 && !evict) {
+                        if ((e[k].t & better) != better) {
+                            wslot = slot;
+                            kind = 1;
+                        } else if (mrz_ones_rank(e[k].t) < my_rank) {
+                            wslot = slot;
+                            kind = 2;
+                            occ_t = e[k].t;
+                            occ_off = e[k].off;
+                        } else if (e[k].t == t) {
+                            if (++round == max_chain) {
+                                evict = true;
+                                kind = 3;
+                            }
+                        }
+                    }
+                    if (e[k].t == t) {
+                        if (nsame < MRZ_SMAX) {
+                            B->same_off[lane][nsame] = e[k].off;
+                            B->same_slot[lane][nsame] = slot;
+                        } else
+                            cplx = true;
+                        nsame++;
+                    }
+                }
+                s += 4;
+                if (walking && ++steps >= MRZ_WALK_STEPS) {
+                    cplx = true;
+                    walking = false;
+                }
+            }
+        }
+    }
+    if (evict && max_chain > MRZ_SMAX) cplx = true;
+    const int len1 = ((fe - h) & smask) + 1;  // slots [h, fe] were read
+
+    // ---- phase 1b: walk of a displaced occupant (src/rzip.c:275-278) ------------
+    int h2 = 0, w2 = -1, kind2 = -1, len2 = 0;
+    {
+        bool walking = act && !cplx && kind == 2;
+        const int rank2 = mrz_ones_rank(occ_t);
+        h2 = (int)(occ_t & C.slot_mask);
+        int s = h2, steps = 0, round2 = 0;
+        while (__ballot(walking)) {
+            if (walking) {
+                mrz_slot e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[k] = tab[(s + k) & smask];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (!walking) continue;
+                    const int slot = (s + k) & smask;
+                    if ((e[k].off | e[k].t) == 0) {
+                        w2 = slot;
+                        kind2 = 0;
+                        walking = false;
+                    } else if ((e[k].t & better) != better) {
+                        w2 = slot;
+                        kind2 = 1;
+                        walking = false;
+                    } else if (mrz_ones_rank(e[k].t) < rank2) {
+                        cplx = true;  // second-level displacement: cooperative path
+                        walking = false;
+                    } else if (e[k].t == occ_t) {
+                        if (++round2 == max_chain) {
+                            cplx = true;
+                            walking = false;
+                        }
+                    }
+                }
+                s += 4;
+                if (walking && ++steps >= MRZ_WALK_STEPS) {
+                    cplx = true;
+                    walking = false;
+                }
+            }
+        }
+        if (w2 >= 0) len2 = ((w2 - h2) & smask) + 1;
+    }
+
+    // ---- phase 2: per-lane match extension (src/rzip.c:372-397) ------------------
+    int64_t best = 0, best_off = 0, best_rev = 0;
+    int hits = 0, misses = 0;
+    {
+        const int ns = nsame < MRZ_SMAX ? nsame : MRZ_SMAX;
+        int k = 0;
+        bool going = act && !cplx && ns > 0;
+        while (__ballot(going)) {
+            if (going) {
+                const int64_t op = B->same_off[lane][k];
+                int64_t ml, rv;
+                bool lng;
+                mrz_lane_match_len(buf, q, op, C.end, L.last_match, &ml, &rv, &lng);
+                if (lng) {
+                    cplx = true;
+                    going = false;
+                } else {
+                    if (ml) {
+                        if (ml > best) {
+                            best = ml;
+                            best_off = op - rv;
+                            best_rev = rv;
+                        }
+                        hits++;
+                    } else
+                        misses++;
+                    if (++k >= ns) going = false;
+                }
+            }
+        }
+    }
+
+    // ---- phase 3: sequential quantities by wave scans ------------------------------
+    const bool ins = do_ins && !cplx;
+    // victim_round for evicting lanes (static victim_round, :259,283-289)
+    const mrz_u64 m_evict = __ballot(ins && kind == 3);
+    if (ins && kind == 3) {
+        const int er = __popcll(m_evict & mrz_low_mask(lane));
+        const int vr = (int)((L.victim_round + er) % max_chain);
+        wslot = B->same_slot[lane][vr];
+    }
+    // hash_count before each lane: saturating prefix sum of the per-lane deltas
+    int d = 0;
+    if (ins) d = (kind == 0) ? 1 : (kind == 2 ? (kind2 == 0 ? 1 : 0) : 0);
+    const int dincl = mrz_wave_incl_sum(d, lane);
+    int64_t c_before = L.count + (dincl - d);
+    if (c_before > C.limit) c_before = C.limit;
+    const bool cull = ins && (c_before + d > C.limit);
+    const mrz_u64 m_cull = __ballot(cull);
+    int cslot = -1;
+    if (m_cull) {
+        // failing entries ahead of tag_clean_ptr (clean_one_from_hash, :313-321)
+        mrz_u64 fmask[MRZ_CULL_WINDOW];
+        int fcum[MRZ_CULL_WINDOW + 1];
+        fcum[0] = 0;
+#pragma unroll
+        for (int b = 0; b < MRZ_CULL_WINDOW; b++) {
+            const int64_t s = L.clean_ptr + b * 64 + lane;
+            mrz_slot e;
+            e.off = 0;
+            e.t = 0;
+            if (s < C.nslots) e = tab[s];
+            fmask[b] = __ballot(((e.off | e.t) != 0) && ((e.t & better) != better));
+            fcum[b + 1] = fcum[b] + __popcll(fmask[b]);
+        }
+        if (cull) {
+            const int cr = __popcll(m_cull & mrz_low_mask(lane));
+            if (cr >= fcum[MRZ_CULL_WINDOW])
+                cplx = true;  // sweep leaves the window (or wraps / promotes): cooperative path
+            else {
+#pragma unroll
+                for (int b = 0; b < MRZ_CULL_WINDOW; b++)
+                    if (cslot < 0 && cr < fcum[b + 1])
+                        cslot = (int)(L.clean_ptr + b * 64 + mrz_select64(fmask[b], cr - fcum[b]));
+            }
+        }
+        // a write that changes the set of failing entries inside the scanned window would
+        // change the sweep: overwrites of failing entries, and -- before the insert mask has
+        // switched to `better` -- any insert (its tag may itself fail `better`)
+        const int64_t win_end = L.clean_ptr + MRZ_CULL_WINDOW * 64;
+        const bool loose = L.tag_mask != better;
+        if (ins && (kind == 1 || loose) && wslot >= L.clean_ptr && wslot < win_end) cplx = true;
+        if (ins && kind == 2 && (kind2 == 1 || loose) && w2 >= L.clean_ptr && w2 < win_end) cplx = true;
+    }
+
+    // ---- phase 4: conflicts with earlier lanes' writes -------------------------------
+    const bool writes = act && !cplx && do_ins;
+    {
+        const unsigned tagv = (epoch << 6) | (unsigned)(63 - lane);
+        if (writes) {
+            atomicMax(&B->filter[mrz_filter_slot(wslot)], tagv);
+            if (kind == 2) atomicMax(&B->filter[mrz_filter_slot(w2)], tagv);
+            if (cslot >= 0) atomicMax(&B->filter[mrz_filter_slot(cslot)], tagv);
+        }
+        MRZ_WAVE_SYNC();
+        bool suspect = false;
+        if (act && !cplx) {
+            // blocks overlapped by [h, h+len1) and [h2, h2+len2)
+            for (int x = h >> 6; !suspect; x = (x + 1) & (smask >> 6)) {
+                const unsigned f = B->filter[((unsigned)x * 2654435761u) >> 20];
+                if ((f >> 6) == epoch && (int)(63 - (f & 63)) < lane) suspect = true;
+                if (x == (((h + len1 - 1) & smask) >> 6)) break;
+            }
+            if (len2 > 0)
+                for (int x = h2 >> 6; !suspect; x = (x + 1) & (smask >> 6)) {
+                    const unsigned f = B->filter[((unsigned)x * 2654435761u) >> 20];
+                    if ((f >> 6) == epoch && (int)(63 - (f & 63)) < lane) suspect = true;
+                    if (x == (((h2 + len2 - 1) & smask) >> 6)) break;
+                }
+        }
+        mrz_u64 m_sus = __ballot(suspect);
+        bool conflict = false;
+        while (m_sus) {
+            const int j = __ffsll((long long)m_sus) - 1;
+            m_sus &= m_sus - 1;
+            const int jh = mrz_lane_read(h, j), jl = mrz_lane_read(len1, j);
+            const int jh2 = mrz_lane_read(h2, j), jl2 = mrz_lane_read(len2, j);
+            bool hitj = false;
+            if (writes && lane < j) {
+                hitj = (((wslot - jh) & smask) < jl) || (jl2 > 0 && ((wslot - jh2) & smask) < jl2);
+                if (kind == 2) hitj = hitj || (((w2 - jh) & smask) < jl) || (jl2 > 0 && ((w2 - jh2) & smask) < jl2);
+                if (cslot >= 0)
+                    hitj = hitj || (((cslot - jh) & smask) < jl) || (jl2 > 0 && ((cslot - jh2) & smask) < jl2);
+            }
+            if (__ballot(hitj) && lane == j) conflict = true;
+        }
+        if (conflict) cplx = true;
+    }
+
+    // ---- cut the batch -------------------------------------------------------------
+    const mrz_u64 m_have = __ballot(have);
+    const mrz_u64 m_cplx = __ballot(have && act && cplx);
+    int n_ok = m_cplx ? __ffsll((long long)m_cplx) - 1 : __popcll(m_have);
+    // the first cull ever switches the insert mask (:583): nothing after it in this batch
+    if (L.tag_mask != better) {
+        const mrz_u64 mc = __ballot(cull && !cplx) & mrz_low_mask(n_ok);
+        if (mc) n_ok = __ffsll((long long)mc);
+    }
+    if (n_ok == 0) return 0;
+
+    // ---- lazy-match fold over the surviving lanes (src/rzip.c:586-599) ---------------
+    int64_t cur_p = L.cur_p, cur_len = L.cur_len, cur_ofs = L.cur_ofs;
+    int emit_lane = -1;
+    {
+        int start = 0;
+        while (true) {
+            const mrz_u64 in_range = mrz_low_mask(n_ok) & ~mrz_low_mask(start);
+            const mrz_u64 m_thr = (cur_len >= MRZ_MIN_MATCH)
+                                      ? (__ballot(act && q >= cur_p + MRZ_MIN_MATCH) & in_range)
+                                      : (__ballot(false) & 0ull);
+            const mrz_u64 m_adopt = __ballot(act && best > cur_len) & in_range;
+            const int e_lane = m_thr ? __ffsll((long long)m_thr) - 1 : 64;
+            const int a_lane = m_adopt ? __ffsll((long long)m_adopt) - 1 : 64;
+            if (e_lane == 64 && a_lane == 64) break;
+            if (e_lane < a_lane) {
+                emit_lane = e_lane;
+                break;
+            }
+            const int64_t aq = mrz_bcast64(q, a_lane);
+            const int64_t ab = mrz_bcast64(best, a_lane);
+            cur_p = aq - mrz_bcast64(best_rev, a_lane);
+            cur_len = ab;
+            cur_ofs = mrz_bcast64(best_off, a_lane);
+            if (cur_len >= MRZ_GREAT_MATCH || aq >= cur_p + MRZ_MIN_MATCH) {
+                emit_lane = a_lane;
+                break;
+            }
+            start = a_lane + 1;
+        }
+    }
+    if (emit_lane >= 0) n_ok = emit_lane + 1;
+    const mrz_u64 keep = mrz_low_mask(n_ok);
+    const bool mine = have && ((keep >> lane) & 1);
+
+    // ---- phase 5: commit -------------------------------------------------------------
+    if (mine && act && do_ins) {
+        if (kind == 2) {
+            mrz_slot o;
+            o.off = occ_off;
+            o.t = occ_t;
+            tab[w2] = o;
+        }
+        mrz_slot n;
+        n.off = q;
+        n.t = t;
+        tab[wslot] = n;
+        if (cslot >= 0) {
+            mrz_slot z;
+            z.off = 0;
+            z.t = 0;
+            tab[cslot] = z;
+        }
+    }
+    const mrz_u64 m_ins = __ballot(mine && act && do_ins);
+    L.inserts += __popcll(m_ins);
+    const int dtot = mrz_lane_read(dincl, n_ok - 1);
+    int64_t cnew = L.count + dtot;
+    if (cnew > C.limit) cnew = C.limit;
+    L.count = cnew;
+    const mrz_u64 m_cull_kept = m_cull & keep;
+    if (m_cull_kept) {
+        const int lastc = 63 - __clzll((long long)m_cull_kept);
+        L.clean_ptr = mrz_lane_read(cslot, lastc);
+        L.tag_mask = better;
+    }
+    L.victim_round = (L.victim_round + __popcll(m_evict & keep)) % max_chain;
+    const int hsum = mrz_wave_incl_sum(mine ? hits : 0, lane);
+    const int msum = mrz_wave_incl_sum(mine ? misses : 0, lane);
+    L.tag_hits += mrz_lane_read(hsum, 63);
+    L.tag_misses += mrz_lane_read(msum, 63);
+    L.cur_p = cur_p;
+    L.cur_len = cur_len;
+    L.cur_ofs = cur_ofs;
+    L.p = mrz_bcast64(q, n_ok - 1);
+    if (emit_lane >= 0) {
+        // the emission itself: cur already adopted, so only the emit half runs
+        *ok = mrz_select_emit(C, L, 0, 0, 0, lane);
+    }
+    return n_ok;
+}
+
 __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_args a) {
     __shared__ int64_t pend_h[MRZ_CASCADE_MAX], pend_t[MRZ_CASCADE_MAX], pend_o[MRZ_CASCADE_MAX];
     __shared__ mrz_mailbox mbox;
+    __shared__ mrz_batch_lds batch;
 
     const int lane = threadIdx.x & 63;
     const int wave = mrz_uni((int)(threadIdx.x >> 6));
-    const uint8_t *__restrict__ buf = a.buf;
-    mrz_slot *tab = a.tab;
     mrz_seq_state *st = a.st;
     mrz_mailbox *mb = &mbox;
 
@@ -362,288 +1068,115 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         mb->done = 0;
         mb->quit = 0;
     }
+    for (int i = threadIdx.x; i < MRZ_FILTER_SIZE; i += MRZ_SEQ_THREADS) batch.filter[i] = 0;
     __syncthreads();
     if (wave != 0) {
-        mrz_helper_loop(buf, mb, wave, lane);
+        mrz_helper_loop(a.buf, mb, wave, lane);
         return;
     }
 
-    const int64_t end = st->end;
-    int64_t p = st->p;
-    int64_t cur_p = st->cur_p, cur_ofs = st->cur_ofs, cur_len = st->cur_len;
-    int64_t last_match = st->last_match;
-    int64_t min_mask = st->min_mask, tag_mask = st->tag_mask;
-    int64_t count = st->count;
-    const int64_t limit = st->limit;
-    int64_t clean_ptr = st->clean_ptr;
-    int64_t victim_round = st->victim_round;
-    const int64_t max_chain = st->max_chain;
-    const int64_t slot_mask = st->slot_mask;
-    const int64_t nslots = slot_mask + 1;
-    int64_t n_events = st->n_events;
-    const int64_t event_cap = st->event_cap;
-    int64_t inserts = st->inserts, tag_hits = st->tag_hits, tag_misses = st->tag_misses;
+    mrz_cfg C;
+    C.buf = a.buf;
+    C.tab = a.tab;
+    C.events = a.events;
+    C.st = st;
+    C.end = st->end;
+    C.limit = st->limit;
+    C.max_chain = st->max_chain;
+    C.slot_mask = st->slot_mask;
+    C.nslots = st->slot_mask + 1;
+    C.event_cap = st->event_cap;
+    mrz_lead L;
+    L.p = st->p;
+    L.cur_p = st->cur_p;
+    L.cur_ofs = st->cur_ofs;
+    L.cur_len = st->cur_len;
+    L.last_match = st->last_match;
+    L.min_mask = st->min_mask;
+    L.tag_mask = st->tag_mask;
+    L.count = st->count;
+    L.clean_ptr = st->clean_ptr;
+    L.victim_round = st->victim_round;
+    L.n_events = st->n_events;
+    L.inserts = st->inserts;
+    L.tag_hits = st->tag_hits;
+    L.tag_misses = st->tag_misses;
 
     const int64_t seg_start = a.seg_start;
     const int64_t seg_end = a.seg_start + a.seg_len;
-    const int64_t lim = (end < seg_end - 1) ? end : seg_end - 1;  // last candidate position of this launch
+    const int64_t lim = (C.end < seg_end - 1) ? C.end : seg_end - 1;  // last candidate position of this launch
     const int64_t nwords = (a.seg_len + 63) / 64;
 
     int64_t win_base = -1;
     mrz_u64 myword = 0;
     int mb_seq = 0;
-    PROF_DECL;
+    unsigned epoch = 1;
+    bool ok = true;
 
-    while (true) {
-        PROF_START();
-        // ---- next position > p whose bitmap bit is set -------------------
-        int64_t q = -1;
-        {
-            int64_t pos = p + 1;
-            if (pos < seg_start) pos = seg_start;
-            while (pos <= lim) {
-                const int64_t wb = seg_start + ((pos - seg_start) >> 12 << 12);
-                if (wb != win_base) {
-                    const int64_t idx = ((wb - seg_start) >> 6) + lane;
-                    myword = idx < nwords ? a.bitmap[idx] : 0ull;
-                    win_base = wb;
-                }
-                const int64_t lane_lo = wb + (int64_t)lane * 64;
-                mrz_u64 w = myword;
-                if (pos > lane_lo) {
-                    const int64_t sh = pos - lane_lo;
-                    w = sh >= 64 ? 0ull : (w >> sh) << sh;
-                }
-                const mrz_u64 m = __ballot(w != 0ull);
-                if (!m) {
-                    pos = wb + 4096;
-                    continue;
-                }
-                const int fl = __ffsll((long long)m) - 1;
-                const mrz_u64 wl = (mrz_u64)mrz_bcast64((int64_t)w, fl);
-                q = wb + (int64_t)fl * 64 + (__ffsll((long long)wl) - 1);
-                break;
-            }
+    while (ok) {
+        // ---- the 4096-position bitmap window that holds position p + 1 ------------
+        int64_t pos = L.p + 1;
+        if (pos < seg_start) pos = seg_start;
+        if (pos > lim) break;
+        const int64_t wb = seg_start + ((pos - seg_start) >> 12 << 12);
+        if (wb != win_base) {
+            const int64_t idx = ((wb - seg_start) >> 6) + lane;
+            myword = idx < nwords ? a.bitmap[idx] : 0ull;
+            win_base = wb;
         }
-        if (q < 0 || q > lim) {
-            // nothing left for this launch
-            if (p < lim) p = lim;
-            break;
+        // this lane's word restricted to [pos, lim]
+        const int64_t lane_lo = wb + (int64_t)lane * 64;
+        mrz_u64 w = myword;
+        if (pos > lane_lo) {
+            const int64_t sh = pos - lane_lo;
+            w = sh >= 64 ? 0ull : (w >> sh) << sh;
         }
-        p = q;
-        PROF_STOP(0);  // candidate discovery
-        const int64_t t = mrz_uni64(a.tags[p - seg_start]);
-        PROF_STOP(1);  // tag fetch
-        PROF_COUNT(8);
-        if ((t & min_mask) != min_mask) continue;  // src/rzip.c:573 with the mask reached by now
-
-        // ---- one pass over the chain: find_best_match (:426-462) and, when this
-        // position is inserted (:579), the probe walk of insert_hash ----------
-        const bool do_insert = (t & tag_mask) == tag_mask;
-        const int64_t better = (min_mask << 1) | 1;
-        const int my_rank = mrz_ones_rank(t);
-        int64_t mlen = 0, m_off = 0, m_rev = 0;
-        bool ins_found = !do_insert;
-        int64_t ins_slot = 0, occ_t = 0, occ_off = 0;
-        int ins_kind = 0;
-        if (do_insert) {
-            inserts++;
-            count++;
+        if (lim < lane_lo + 63) {
+            const int64_t keepbits = lim - lane_lo + 1;
+            w = keepbits <= 0 ? 0ull : (w & mrz_low_mask((int)keepbits));
         }
-        {
-            const int64_t h0 = t & slot_mask;
-            int64_t round = 0, victim_h = 0;
-            for (int64_t b = 0;; b += MRZ_WAVE) {
-                const int64_t s = (h0 + b + lane) & slot_mask;
-                const mrz_slot e = tab[s];
-                const bool empty = (e.off | e.t) == 0;
-                const mrz_u64 m_empty = __ballot(empty);
-                PROF_STOP(2);  // chain load
-                const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : MRZ_WAVE;
-                if (!ins_found)
-                    ins_found = mrz_insert_step(e, empty, t, my_rank, h0 + b, slot_mask, better, max_chain, &round,
-                                                &victim_h, &count, &victim_round, &ins_slot, &ins_kind, &occ_t,
-                                                &occ_off);
-                const mrz_u64 m_same = __ballot(!empty && e.t == t) & mrz_low_mask(first_empty);
-                PROF_STOP(3);  // classify
-                PROF_COUNT(9);
-                if (m_same) {
-                    PROF_COUNT(10);
-                    // tag-equal entries of this step, probe order, 8 per pass
-                    mrz_u64 todo = m_same;
-                    while (todo) {
-                        // the g-th remaining entry goes to lane group g
-                        const int g = lane >> 3;
-                        mrz_u64 tmp = todo;
-                        int src_lane = -1, npass = 0;
-                        for (int k = 0; k < 8 && tmp; k++) {
-                            const int sl = __ffsll((long long)tmp) - 1;
-                            tmp &= tmp - 1;
-                            if (k == g) src_lane = sl;
-                            npass++;
-                        }
-                        const bool valid = src_lane >= 0;
-                        const int rd = valid ? src_lane : 0;
-                        const int lo = __shfl((int)(uint32_t)(uint64_t)e.off, rd, MRZ_WAVE);
-                        const int hi = __shfl((int)(uint32_t)((uint64_t)e.off >> 32), rd, MRZ_WAVE);
-                        const int64_t op = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-                        int64_t g_len, g_rev;
-                        bool g_long;
-                        mrz_short_match_len(buf, p, op, valid, end, last_match, lane, &g_len, &g_rev, &g_long);
-                        for (int k = 0; k < npass; k++) {
-                            int64_t ml = mrz_bcast64(g_len, 8 * k);
-                            int64_t rv = mrz_bcast64(g_rev, 8 * k);
-                            const int64_t opk = mrz_bcast64(op, 8 * k);
-                            if (mrz_lane_read(g_long ? 1 : 0, 8 * k))
-                                ml = mrz_long_match_len(buf, mb, &mb_seq, p, opk, end, last_match, &rv, lane);
-                            if (ml) {  // first longest wins, :446-450
-                                if (ml > mlen) {
-                                    mlen = ml;
-                                    m_off = opk - rv;
-                                    m_rev = rv;
-                                }
-                                tag_hits++;
-                            } else
-                                tag_misses++;
-                        }
-                        todo = tmp;
-                    }
-                    PROF_STOP(4);  // match jobs
-                }
-                if (first_empty < MRZ_WAVE) break;
-            }
+        const mrz_u64 any = __ballot(w != 0ull);
+        if (!any) {
+            // nothing left in this window
+            const int64_t nxt = wb + 4096;
+            L.p = (nxt - 1 < lim) ? nxt - 1 : lim;
+            continue;
         }
-
-        // ---- insert + cull (:579-584) -------------------------------------
-        if (do_insert) {
-            int np = 0;
-            int64_t it = t, io = p;
-            while (true) {
-                if (np >= MRZ_CASCADE_MAX) {  // cannot happen: every level has a strictly lower rank
-                    if (lane == 0) st->error = 2;
-                    np = 0;
-                    break;
-                }
-                if (lane == 0) {
-                    pend_h[np] = ins_slot;
-                    pend_t[np] = it;
-                    pend_o[np] = io;
-                }
-                np++;
-                if (ins_kind != 2) break;
-                // re-insert the displaced occupant: its own probe walk
-                it = occ_t;
-                io = occ_off;
-                const int64_t h0 = it & slot_mask;
-                const int rank2 = mrz_ones_rank(it);
-                int64_t round = 0, victim_h = 0;
-                for (int64_t b = 0;; b += MRZ_WAVE) {
-                    const int64_t s = (h0 + b + lane) & slot_mask;
-                    const mrz_slot e = tab[s];
-                    const bool empty = (e.off | e.t) == 0;
-                    if (mrz_insert_step(e, empty, it, rank2, h0 + b, slot_mask, better, max_chain, &round, &victim_h,
-                                        &count, &victim_round, &ins_slot, &ins_kind, &occ_t, &occ_off))
-                        break;
-                }
-            }
-            // write back innermost-first (the recursion's return order)
-            while (np-- > 0) {
-                const int64_t hs = mrz_uni64(pend_h[np]);
-                if (lane == 0) {
-                    mrz_slot w;
-                    w.off = pend_o[np];
-                    w.t = pend_t[np];
-                    tab[hs] = w;
-                }
-            }
-            PROF_STOP(5);  // insert write-back / cascades
-            if (count > limit) {
-                // clean_one_from_hash (:305-328)
-                while (true) {
-                    const int64_t better2 = (min_mask << 1) | 1;
-                    bool culled = false;
-                    while (clean_ptr < nslots) {
-                        const int64_t s = clean_ptr + lane;
-                        mrz_slot e;
-                        e.off = 0;
-                        e.t = 0;
-                        if (s < nslots) e = tab[s];
-                        const bool hit = ((e.off | e.t) != 0) && ((e.t & better2) != better2);
-                        const mrz_u64 m = __ballot(hit);
-                        if (m) {
-                            const int fl = __ffsll((long long)m) - 1;
-                            clean_ptr += fl;
-                            if (lane == fl) {
-                                mrz_slot z;
-                                z.off = 0;
-                                z.t = 0;
-                                tab[s] = z;
-                            }
-                            count--;
-                            culled = true;
-                            break;
-                        }
-                        clean_ptr += MRZ_WAVE;
-                    }
-                    if (culled) {
-                        tag_mask = better2;
-                        break;
-                    }
-                    min_mask = better2;
-                    clean_ptr = 0;
-                }
-            }
+        int used = 0;
+#ifndef MRZ_NO_BATCH
+        used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, lane, &ok);
+        epoch++;
+#endif
+        if (used == 0 && ok) {
+            // first candidate of the window through the cooperative path
+            const int fl = __ffsll((long long)any) - 1;
+            const mrz_u64 wl = (mrz_u64)mrz_bcast64((int64_t)w, fl);
+            L.p = wb + (int64_t)fl * 64 + (__ffsll((long long)wl) - 1);
+            const int64_t t = mrz_uni64(a.tags[L.p - seg_start]);
+            if ((t & L.min_mask) == L.min_mask)  // src/rzip.c:573 with the mask reached by now
+                ok = mrz_seq_candidate(C, L, mb, &mb_seq, pend_h, pend_t, pend_o, t, lane);
         }
-
-        PROF_STOP(6);  // cull
-        // ---- lazy selection + emission (:586-599) -------------------------
-        if (mlen > cur_len) {
-            cur_p = p - m_rev;
-            cur_len = mlen;
-            cur_ofs = m_off;
-        }
-        if ((cur_len >= MRZ_GREAT_MATCH || p >= cur_p + MRZ_MIN_MATCH) && cur_len >= MRZ_MIN_MATCH) {
-            if (n_events >= event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
-                if (lane == 0) st->error = 1;
-                break;
-            }
-            if (lane == 0) {
-                mrz_event ev;
-                ev.p = cur_p;
-                ev.ofs = cur_ofs;
-                ev.len = cur_len;
-                a.events[n_events] = ev;
-            }
-            n_events++;
-            last_match = cur_p + cur_len;
-            cur_p = p = last_match;
-            cur_len = 0;
-        }
-        PROF_STOP(7);  // select / emit
     }
 
     // release the helpers, then publish the state for the next segment's launch
     if (lane == 0) {
         mrz_mb_store(&mb->quit, 1);
         mrz_mb_store(&mb->seq, mb_seq + 1);
-        st->p = p;
-        st->cur_p = cur_p;
-        st->cur_ofs = cur_ofs;
-        st->cur_len = cur_len;
-        st->last_match = last_match;
-        st->min_mask = min_mask;
-        st->tag_mask = tag_mask;
-        st->count = count;
-        st->clean_ptr = clean_ptr;
-        st->victim_round = victim_round;
-        st->n_events = n_events;
-        st->inserts = inserts;
-        st->tag_hits = tag_hits;
-        st->tag_misses = tag_misses;
-        st->finished = p >= end ? 1 : 0;
-#ifdef MRZ_SEQ_PROFILE
-        for (int k = 0; k < 16; k++) st->prof[k] += prof_acc[k];
-#endif
+        st->p = L.p;
+        st->cur_p = L.cur_p;
+        st->cur_ofs = L.cur_ofs;
+        st->cur_len = L.cur_len;
+        st->last_match = L.last_match;
+        st->min_mask = L.min_mask;
+        st->tag_mask = L.tag_mask;
+        st->count = L.count;
+        st->clean_ptr = L.clean_ptr;
+        st->victim_round = L.victim_round;
+        st->n_events = L.n_events;
+        st->inserts = L.inserts;
+        st->tag_hits = L.tag_hits;
+        st->tag_misses = L.tag_misses;
+        st->finished = L.p >= C.end ? 1 : 0;
     }
 }
 

@@ -62,6 +62,14 @@ def test_long_match_pieces(emu_lib, oracle):
     _parity.check_chunk(emu_lib, oracle, blk + blk)
 
 
+def test_batch_engine_culling_and_mask_promotion(emu_lib, oracle):
+    """Level 1 (2 MiB table): the table fills, the first cull switches the insert mask,
+    sweeps complete and minimum_tag_mask is promoted -- all inside batch mode."""
+    want = _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(3 << 20, seed=3), level=1, table=True)
+    assert want["min_mask"] > 15 and want["stats"]["inserts"] > want["hash_count"]
+    _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 20, seed=4), level=1, table=True)
+
+
 def test_crc32_kernel(emu_lib):
     with m.RzipContext(lib=emu_lib) as ctx:
         for n in (0, 1, 15, 16, 17, 1000, 65535, 65536, 65537, 3 * 65536 + 77):
