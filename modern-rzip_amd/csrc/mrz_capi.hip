@@ -420,9 +420,9 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->hash_count = hs.count;
     res->n_events = E;
     if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[16] = { "find", "tag", "chainload", "classify", "matchjobs", "insert", "cull",
-                                         "emit", "n_cand", "n_steps", "n_hitsteps", "", "", "", "", "" };
-        for (int k = 0; k < 11; k++) fprintf(stderr, "prof %-10s %lld\n", names[k], (long long)hs.prof[k]);
+        static const char *names[16] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
+                                         "cut_cull", "batch_emits", "cut_cascade", "pairs", "formed", "", "", "", "", "" };
+        for (int k = 0; k < 11; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

@@ -40,7 +40,7 @@
 #include "mrz_device.h"
 
 #ifndef MRZ_SEQ_WAVES
-#define MRZ_SEQ_WAVES 16
+#define MRZ_SEQ_WAVES 8  // 512 threads: 256 VGPRs per lane, no spills in the batch engine
 #endif
 #define MRZ_SEQ_THREADS (64 * MRZ_SEQ_WAVES)
 #define MRZ_CASCADE_MAX 64
@@ -573,17 +573,24 @@ __device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_mail
 //   5. all surviving lanes write their slots in one go.
 // The committed prefix is exactly what the reference's loop would have done.
 #define MRZ_SMAX 16
-#define MRZ_WALK_STEPS 24
+#define MRZ_WALK_SLOTS 8   // slots (16 B each) a lane loads per walk step: one 128-B line when aligned
+#define MRZ_WALK_STEPS 12
 #define MRZ_FILTER_SIZE 4096
 #define MRZ_CULL_WINDOW 4  // x 64 slots scanned ahead of tag_clean_ptr per batch
 
 struct mrz_batch_lds {
     int pref[64];
     mrz_u64 word[64];
+    int64_t qpos[64];
     int64_t same_off[64][MRZ_SMAX];
     int same_slot[64][MRZ_SMAX];
+    int pair_res[64][MRZ_SMAX];  // (len << 8) | rev, or -1 = needs the cooperative path
     unsigned filter[MRZ_FILTER_SIZE];
 };
+
+// diagnostics kept in mrz_seq_state.prof (always on, a handful of scalar adds)
+enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT,
+       MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED, MRZ_ST_N };
 
 #ifdef __HIP_DEVICE_COMPILE__
 #define MRZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
@@ -689,7 +696,8 @@ __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64
 // first candidate has to go through mrz_seq_candidate.  `w` is this lane's bitmap
 // word of the 4096-position window starting at `wb`, already masked to (L.p, lim].
 __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_lds *B, const int64_t *__restrict__ tags,
-                                     int64_t seg_start, int64_t wb, mrz_u64 w, unsigned epoch, int lane, bool *ok) {
+                                     int64_t seg_start, int64_t wb, mrz_u64 w, unsigned epoch, int width, int lane,
+                                     bool *ok, int64_t *stat) {
     const uint8_t *__restrict__ buf = C.buf;
     mrz_slot *tab = C.tab;
     const int smask = (int)C.slot_mask;
@@ -701,7 +709,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     const int cnt = __popcll(w);
     const int incl = mrz_wave_incl_sum(cnt, lane);
     const int total = mrz_lane_read(incl, 63);
-    const int nb = total < 64 ? total : 64;
+    const int nb = total < width ? total : width;
     B->pref[lane] = incl - cnt;
     B->word[lane] = w;
     MRZ_WAVE_SYNC();
@@ -729,17 +737,18 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     int fe = -1, wslot = -1, kind = -1;  // kind: 0 empty, 1 overwrite, 2 displace, 3 evict
     int nsame = 0, round = 0;
     bool cplx = false, evict = false;
+    int why = 0;  // first reason this lane needs the cooperative path (diagnostics)
     int64_t occ_t = 0, occ_off = 0;
     {
         bool walking = act;
         int s = h, steps = 0;
         while (__ballot(walking)) {
             if (walking) {
-                mrz_slot e[4];
+                mrz_slot e[MRZ_WALK_SLOTS];
 #pragma unroll
-                for (int k = 0; k < 4; k++) e[k] = tab[(s + k) & smask];
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) e[k] = tab[(s + k) & smask];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) {
                     if (!walking) continue;
                     const int slot = (s + k) & smask;
                     if ((e[k].off | e[k].t) == 0) {
@@ -771,20 +780,26 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
                         if (nsame < MRZ_SMAX) {
                             B->same_off[lane][nsame] = e[k].off;
                             B->same_slot[lane][nsame] = slot;
-                        } else
+                        } else {
                             cplx = true;
+                            if (!why) why = MRZ_ST_CUT_WALK;
+                        }
                         nsame++;
                     }
                 }
-                s += 4;
+                s += MRZ_WALK_SLOTS;
                 if (walking && ++steps >= MRZ_WALK_STEPS) {
                     cplx = true;
+                    if (!why) why = MRZ_ST_CUT_WALK;
                     walking = false;
                 }
             }
         }
     }
-    if (evict && max_chain > MRZ_SMAX) cplx = true;
+    if (evict && max_chain > MRZ_SMAX) {
+        cplx = true;
+        if (!why) why = MRZ_ST_CUT_WALK;
+    }
     const int len1 = ((fe - h) & smask) + 1;  // slots [h, fe] were read
 
     // ---- phase 1b: walk of a displaced occupant (src/rzip.c:275-278) ------------
@@ -796,11 +811,11 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         int s = h2, steps = 0, round2 = 0;
         while (__ballot(walking)) {
             if (walking) {
-                mrz_slot e[4];
+                mrz_slot e[MRZ_WALK_SLOTS];
 #pragma unroll
-                for (int k = 0; k < 4; k++) e[k] = tab[(s + k) & smask];
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) e[k] = tab[(s + k) & smask];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) {
                     if (!walking) continue;
                     const int slot = (s + k) & smask;
                     if ((e[k].off | e[k].t) == 0) {
@@ -813,17 +828,20 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
                         walking = false;
                     } else if (mrz_ones_rank(e[k].t) < rank2) {
                         cplx = true;  // second-level displacement: cooperative path
+                        if (!why) why = MRZ_ST_CUT_CASCADE;
                         walking = false;
                     } else if (e[k].t == occ_t) {
                         if (++round2 == max_chain) {
                             cplx = true;
+                            if (!why) why = MRZ_ST_CUT_CASCADE;
                             walking = false;
                         }
                     }
                 }
-                s += 4;
+                s += MRZ_WALK_SLOTS;
                 if (walking && ++steps >= MRZ_WALK_STEPS) {
                     cplx = true;
+                    if (!why) why = MRZ_ST_CUT_WALK;
                     walking = false;
                 }
             }
@@ -831,35 +849,58 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         if (w2 >= 0) len2 = ((w2 - h2) & smask) + 1;
     }
 
-    // ---- phase 2: per-lane match extension (src/rzip.c:372-397) ------------------
+    // ---- phase 2: match extension (src/rzip.c:372-397), one (candidate, entry) pair per
+    // lane per round: the pairs of all lanes are laid end to end and dealt out 64 at a time
     int64_t best = 0, best_off = 0, best_rev = 0;
     int hits = 0, misses = 0;
     {
-        const int ns = nsame < MRZ_SMAX ? nsame : MRZ_SMAX;
-        int k = 0;
-        bool going = act && !cplx && ns > 0;
-        while (__ballot(going)) {
-            if (going) {
-                const int64_t op = B->same_off[lane][k];
-                int64_t ml, rv;
-                bool lng;
-                mrz_lane_match_len(buf, q, op, C.end, L.last_match, &ml, &rv, &lng);
-                if (lng) {
-                    cplx = true;
-                    going = false;
-                } else {
-                    if (ml) {
-                        if (ml > best) {
-                            best = ml;
-                            best_off = op - rv;
-                            best_rev = rv;
-                        }
-                        hits++;
-                    } else
-                        misses++;
-                    if (++k >= ns) going = false;
+        const int ns = (act && !cplx) ? (nsame < MRZ_SMAX ? nsame : MRZ_SMAX) : 0;
+        const int pincl = mrz_wave_incl_sum(ns, lane);
+        const int npairs = mrz_lane_read(pincl, 63);
+        if (npairs) {
+            B->pref[lane] = pincl - ns;
+            B->qpos[lane] = q;
+            MRZ_WAVE_SYNC();
+            for (int base = 0; base < npairs; base += 64) {
+                const int i = base + lane;
+                if (i < npairs) {
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (B->pref[mid] <= i)
+                            lo = mid;
+                        else
+                            hi = mid - 1;
+                    }
+                    const int k = i - B->pref[lo];
+                    int64_t ml, rv;
+                    bool lng;
+                    mrz_lane_match_len(buf, B->qpos[lo], B->same_off[lo][k], C.end, L.last_match, &ml, &rv, &lng);
+                    B->pair_res[lo][k] = lng ? -1 : (int)((ml << 8) | rv);
                 }
             }
+            MRZ_WAVE_SYNC();
+            // every owner folds its entries in probe order: first longest wins (:446-450)
+            for (int k = 0; k < ns; k++) {
+                const int r = B->pair_res[lane][k];
+                if (r < 0) {
+                    cplx = true;
+                    if (!why) why = MRZ_ST_CUT_LONG;
+                    break;
+                }
+                const int64_t ml = r >> 8, rv = r & 0xff;
+                if (ml) {
+                    if (ml > best) {
+                        best = ml;
+                        best_off = B->same_off[lane][k] - rv;
+                        best_rev = rv;
+                    }
+                    hits++;
+                } else
+                    misses++;
+            }
+            stat[MRZ_ST_PAIRS] += npairs;
         }
     }
 
@@ -898,8 +939,10 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         }
         if (cull) {
             const int cr = __popcll(m_cull & mrz_low_mask(lane));
-            if (cr >= fcum[MRZ_CULL_WINDOW])
+            if (cr >= fcum[MRZ_CULL_WINDOW]) {
                 cplx = true;  // sweep leaves the window (or wraps / promotes): cooperative path
+                if (!why) why = MRZ_ST_CUT_CULL;
+            }
             else {
 #pragma unroll
                 for (int b = 0; b < MRZ_CULL_WINDOW; b++)
@@ -912,8 +955,14 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         // switched to `better` -- any insert (its tag may itself fail `better`)
         const int64_t win_end = L.clean_ptr + MRZ_CULL_WINDOW * 64;
         const bool loose = L.tag_mask != better;
-        if (ins && (kind == 1 || loose) && wslot >= L.clean_ptr && wslot < win_end) cplx = true;
-        if (ins && kind == 2 && (kind2 == 1 || loose) && w2 >= L.clean_ptr && w2 < win_end) cplx = true;
+        if (ins && (kind == 1 || loose) && wslot >= L.clean_ptr && wslot < win_end) {
+            cplx = true;
+            if (!why) why = MRZ_ST_CUT_CULL;
+        }
+        if (ins && kind == 2 && (kind2 == 1 || loose) && w2 >= L.clean_ptr && w2 < win_end) {
+            cplx = true;
+            if (!why) why = MRZ_ST_CUT_CULL;
+        }
     }
 
     // ---- phase 4: conflicts with earlier lanes' writes -------------------------------
@@ -957,13 +1006,21 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
             }
             if (__ballot(hitj) && lane == j) conflict = true;
         }
-        if (conflict) cplx = true;
+        if (conflict) {
+            cplx = true;
+            if (!why) why = MRZ_ST_CUT_CONFLICT;
+        }
     }
 
     // ---- cut the batch -------------------------------------------------------------
     const mrz_u64 m_have = __ballot(have);
     const mrz_u64 m_cplx = __ballot(have && act && cplx);
     int n_ok = m_cplx ? __ffsll((long long)m_cplx) - 1 : __popcll(m_have);
+    stat[MRZ_ST_BATCH_FORMED] += __popcll(m_have);
+    if (m_cplx) {
+        const int reason = mrz_lane_read(why, __ffsll((long long)m_cplx) - 1);
+        if (reason > 0 && reason < MRZ_ST_N) stat[reason] += 1;
+    }
     // the first cull ever switches the insert mask (:583): nothing after it in this batch
     if (L.tag_mask != better) {
         const mrz_u64 mc = __ballot(cull && !cplx) & mrz_low_mask(n_ok);
@@ -1001,7 +1058,12 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
             start = a_lane + 1;
         }
     }
-    if (emit_lane >= 0) n_ok = emit_lane + 1;
+    if (emit_lane >= 0) {
+        n_ok = emit_lane + 1;
+        stat[MRZ_ST_BATCH_EMITS] += 1;
+    }
+    stat[MRZ_ST_BATCHES] += 1;
+    stat[MRZ_ST_BATCH_LANES] += n_ok;
     const mrz_u64 keep = mrz_low_mask(n_ok);
     const bool mine = have && ((keep >> lane) & 1);
 
@@ -1112,6 +1174,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     int mb_seq = 0;
     unsigned epoch = 1;
     bool ok = true;
+    int width = 64;            // batch width, adapted to how many lanes recent batches could commit
+    bool prefer_seq = false;   // right after an emission the next candidate is usually a long match
+    int64_t stat[MRZ_ST_N];
+    for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
 
     while (ok) {
         // ---- the 4096-position bitmap window that holds position p + 1 ------------
@@ -1143,11 +1209,23 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             continue;
         }
         int used = 0;
+        const int64_t ev_before = L.n_events;
 #ifndef MRZ_NO_BATCH
-        used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, lane, &ok);
-        epoch++;
+        if (!prefer_seq) {
+            used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, width, lane, &ok, stat);
+            epoch++;
+            // adapt the width: shrink towards what could be committed, grow back when all of it was
+            if (used >= width)
+                width = width * 2 > 64 ? 64 : width * 2;
+            else {
+                const int want = 2 * used + 4;
+                width = want < 8 ? 8 : (want > 64 ? 64 : want);
+            }
+        }
 #endif
+        prefer_seq = false;
         if (used == 0 && ok) {
+            stat[MRZ_ST_SEQ] += 1;
             // first candidate of the window through the cooperative path
             const int fl = __ffsll((long long)any) - 1;
             const mrz_u64 wl = (mrz_u64)mrz_bcast64((int64_t)w, fl);
@@ -1156,6 +1234,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             if ((t & L.min_mask) == L.min_mask)  // src/rzip.c:573 with the mask reached by now
                 ok = mrz_seq_candidate(C, L, mb, &mb_seq, pend_h, pend_t, pend_o, t, lane);
         }
+        if (L.n_events != ev_before) prefer_seq = true;
     }
 
     // release the helpers, then publish the state for the next segment's launch
@@ -1177,6 +1256,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         st->tag_hits = L.tag_hits;
         st->tag_misses = L.tag_misses;
         st->finished = L.p >= C.end ? 1 : 0;
+        for (int k = 0; k < MRZ_ST_N; k++) st->prof[k] += stat[k];
     }
 }
 
