@@ -420,9 +420,10 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->hash_count = hs.count;
     res->n_events = E;
     if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[16] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
-                                         "cut_cull", "batch_emits", "cut_cascade", "pairs", "formed", "", "", "", "", "" };
-        for (int k = 0; k < 11; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
+        static const char *names[20] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
+                                         "cut_cull", "batch_emits", "cut_cascade", "pairs", "formed", "t_form", "t_walk",
+                                         "t_walk2", "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window" };
+        for (int k = 0; k < 20; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

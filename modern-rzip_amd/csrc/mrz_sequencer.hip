@@ -47,20 +47,16 @@
 
 // optional in-kernel cycle accounting (diagnostic builds only: -DMRZ_SEQ_PROFILE)
 #ifdef MRZ_SEQ_PROFILE
-#define PROF_DECL int64_t prof_t0 = 0, prof_acc[16] = { 0 }
-#define PROF_START() prof_t0 = (int64_t)__builtin_amdgcn_s_memtime()
-#define PROF_STOP(k)                                                     \
+#define PROF_T0() int64_t prof_t0 = (int64_t)__builtin_amdgcn_s_memtime()
+#define PROF_ADD(k)                                                      \
     do {                                                                 \
         const int64_t now__ = (int64_t)__builtin_amdgcn_s_memtime();     \
-        prof_acc[k] += now__ - prof_t0;                                  \
+        stat[k] += now__ - prof_t0;                                      \
         prof_t0 = now__;                                                 \
     } while (0)
-#define PROF_COUNT(k) prof_acc[k] += 1
 #else
-#define PROF_DECL
-#define PROF_START()
-#define PROF_STOP(k)
-#define PROF_COUNT(k)
+#define PROF_T0()
+#define PROF_ADD(k)
 #endif
 
 struct mrz_seq_args {
@@ -167,13 +163,18 @@ __device__ static int64_t mrz_wave_bwd(const uint8_t *__restrict__ buf, int64_t 
 }
 
 // Long candidate: the forward extension is striped over every wave of the
-// workgroup (W x 4 KiB per round); the leader folds the per-wave results.
+// workgroup (W x 4 KiB per round); the leader folds the per-wave results and does
+// the backward extension while the helpers are busy with the first round.
 __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int *mb_seq, int64_t p0,
                                              int64_t op, int64_t end, int64_t last_match, int64_t *rev_out, int lane) {
     *rev_out = 0;
     if (op >= p0) return 0;
     const int64_t maxf = end - p0;
-    int64_t fwd = 0;
+    const int64_t floor_p = last_match > 0 ? last_match : 0;
+    int64_t maxb = p0 - floor_p;
+    if (op < maxb) maxb = op;
+    int64_t fwd = 0, rev = 0;
+    bool have_rev = false;
     if (maxf > 0) {
         for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * MRZ_STRIPE) {
             if (MRZ_SEQ_WAVES > 1) {
@@ -188,6 +189,10 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
                 if (lane == 0) mrz_mb_store(&mb->seq, *mb_seq);
             }
             int64_t best = mrz_wave_fwd_stripe(buf, p0, op, maxf, base, lane);  // the leader's own stripe (wave 0)
+            if (!have_rev) {
+                rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
+                have_rev = true;
+            }
             if (MRZ_SEQ_WAVES > 1) {
                 while (mrz_uni(mrz_mb_load(&mb->done)) < MRZ_SEQ_WAVES - 1) __builtin_amdgcn_s_sleep(1);
                 for (int w = 1; w < MRZ_SEQ_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
@@ -198,10 +203,7 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
             }
         }
     }
-    const int64_t floor_p = last_match > 0 ? last_match : 0;
-    int64_t maxb = p0 - floor_p;
-    if (op < maxb) maxb = op;
-    const int64_t rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
+    if (!have_rev) rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
     *rev_out = rev;
     const int64_t len = fwd + rev;
     return len < MRZ_MIN_MATCH ? 0 : len;
@@ -590,7 +592,9 @@ struct mrz_batch_lds {
 
 // diagnostics kept in mrz_seq_state.prof (always on, a handful of scalar adds)
 enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT,
-       MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED, MRZ_ST_N };
+       MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED,
+       MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_WALK2, MRZ_ST_T_PAIRS, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_COMMIT,
+       MRZ_ST_T_SEQ, MRZ_ST_T_WINDOW, MRZ_ST_N };
 
 #ifdef __HIP_DEVICE_COMPILE__
 #define MRZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
@@ -697,13 +701,14 @@ __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64
 // word of the 4096-position window starting at `wb`, already masked to (L.p, lim].
 __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_lds *B, const int64_t *__restrict__ tags,
                                      int64_t seg_start, int64_t wb, mrz_u64 w, unsigned epoch, int width, int lane,
-                                     bool *ok, int64_t *stat) {
+                                     bool *ok, int64_t *stat, mrz_mailbox *mb, int *mb_seq) {
     const uint8_t *__restrict__ buf = C.buf;
     mrz_slot *tab = C.tab;
     const int smask = (int)C.slot_mask;
     const int max_chain = (int)C.max_chain;
     const int64_t better = (L.min_mask << 1) | 1;
     *ok = true;
+    PROF_T0();
 
     // ---- formation: lane r takes the r-th candidate of the window ------------
     const int cnt = __popcll(w);
@@ -731,6 +736,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     const bool act = have && (t & L.min_mask) == L.min_mask;
     const bool do_ins = act && (t & L.tag_mask) == L.tag_mask;
 
+    PROF_ADD(MRZ_ST_T_FORM);
     // ---- phase 1: per-lane probe walk ------------------------------------------
     const int h = (int)(t & C.slot_mask);
     const int my_rank = mrz_ones_rank(t);
@@ -802,6 +808,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     }
     const int len1 = ((fe - h) & smask) + 1;  // slots [h, fe] were read
 
+    PROF_ADD(MRZ_ST_T_WALK);
     // ---- phase 1b: walk of a displaced occupant (src/rzip.c:275-278) ------------
     int h2 = 0, w2 = -1, kind2 = -1, len2 = 0;
     {
@@ -849,10 +856,12 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         if (w2 >= 0) len2 = ((w2 - h2) & smask) + 1;
     }
 
+    PROF_ADD(MRZ_ST_T_WALK2);
     // ---- phase 2: match extension (src/rzip.c:372-397), one (candidate, entry) pair per
     // lane per round: the pairs of all lanes are laid end to end and dealt out 64 at a time
     int64_t best = 0, best_off = 0, best_rev = 0;
     int hits = 0, misses = 0;
+    bool needs_long = false;  // some entry runs past the 64-byte reach: resolved cooperatively at the cut
     {
         const int ns = (act && !cplx) ? (nsame < MRZ_SMAX ? nsame : MRZ_SMAX) : 0;
         const int pincl = mrz_wave_incl_sum(ns, lane);
@@ -882,13 +891,10 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
             }
             MRZ_WAVE_SYNC();
             // every owner folds its entries in probe order: first longest wins (:446-450)
-            for (int k = 0; k < ns; k++) {
+            for (int k = 0; k < ns; k++)
+                if (B->pair_res[lane][k] < 0) needs_long = true;
+            for (int k = 0; k < ns && !needs_long; k++) {
                 const int r = B->pair_res[lane][k];
-                if (r < 0) {
-                    cplx = true;
-                    if (!why) why = MRZ_ST_CUT_LONG;
-                    break;
-                }
                 const int64_t ml = r >> 8, rv = r & 0xff;
                 if (ml) {
                     if (ml > best) {
@@ -904,6 +910,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         }
     }
 
+    PROF_ADD(MRZ_ST_T_PAIRS);
     // ---- phase 3: sequential quantities by wave scans ------------------------------
     const bool ins = do_ins && !cplx;
     // victim_round for evicting lanes (static victim_round, :259,283-289)
@@ -965,6 +972,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         }
     }
 
+    PROF_ADD(MRZ_ST_T_SCANS);
     // ---- phase 4: conflicts with earlier lanes' writes -------------------------------
     const bool writes = act && !cplx && do_ins;
     {
@@ -1012,21 +1020,65 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         }
     }
 
+    PROF_ADD(MRZ_ST_T_CONFLICT);
     // ---- cut the batch -------------------------------------------------------------
     const mrz_u64 m_have = __ballot(have);
     const mrz_u64 m_cplx = __ballot(have && act && cplx);
-    int n_ok = m_cplx ? __ffsll((long long)m_cplx) - 1 : __popcll(m_have);
+    const mrz_u64 m_long = __ballot(have && act && !cplx && needs_long);
+    const mrz_u64 m_stop_any = m_cplx | m_long;
+    int n_ok = m_stop_any ? __ffsll((long long)m_stop_any) - 1 : __popcll(m_have);
     stat[MRZ_ST_BATCH_FORMED] += __popcll(m_have);
-    if (m_cplx) {
-        const int reason = mrz_lane_read(why, __ffsll((long long)m_cplx) - 1);
+    if (m_stop_any && ((m_cplx >> n_ok) & 1)) {
+        const int reason = mrz_lane_read(why, n_ok);
         if (reason > 0 && reason < MRZ_ST_N) stat[reason] += 1;
+    } else if (m_stop_any) {
+        // The cut lane is sound except that some of its tag-equal entries run past the per-lane
+        // reach: extend those with the whole workgroup (striped long path), fold the lane's
+        // entries in probe order, and keep the lane as the last one of this batch.
+        const int x = n_ok;
+        stat[MRZ_ST_CUT_LONG] += 1;
+        const int nsx = mrz_lane_read(nsame < MRZ_SMAX ? nsame : MRZ_SMAX, x);
+        const int64_t qx = mrz_bcast64(q, x);
+        int64_t xb = 0, xoff = 0, xrev = 0;
+        int xh = 0, xm = 0;
+        for (int k = 0; k < nsx; k++) {
+            const int r = mrz_uni(B->pair_res[x][k]);
+            const int64_t op = mrz_uni64(B->same_off[x][k]);
+            int64_t ml, rv;
+            if (r < 0)
+                ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane);
+            else {
+                ml = r >> 8;
+                rv = r & 0xff;
+            }
+            if (ml) {  // first longest wins, :446-450
+                if (ml > xb) {
+                    xb = ml;
+                    xoff = op - rv;
+                    xrev = rv;
+                }
+                xh++;
+            } else
+                xm++;
+        }
+        if (lane == x) {
+            best = xb;
+            best_off = xoff;
+            best_rev = xrev;
+            hits = xh;
+            misses = xm;
+        }
+        n_ok = x + 1;
     }
     // the first cull ever switches the insert mask (:583): nothing after it in this batch
     if (L.tag_mask != better) {
         const mrz_u64 mc = __ballot(cull && !cplx) & mrz_low_mask(n_ok);
         if (mc) n_ok = __ffsll((long long)mc);
     }
-    if (n_ok == 0) return 0;
+    if (n_ok == 0) {
+        PROF_ADD(MRZ_ST_T_COMMIT);
+        return 0;
+    }
 
     // ---- lazy-match fold over the surviving lanes (src/rzip.c:586-599) ---------------
     int64_t cur_p = L.cur_p, cur_len = L.cur_len, cur_ofs = L.cur_ofs;
@@ -1111,6 +1163,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         // the emission itself: cur already adopted, so only the emit half runs
         *ok = mrz_select_emit(C, L, 0, 0, 0, lane);
     }
+    PROF_ADD(MRZ_ST_T_COMMIT);
     return n_ok;
 }
 
@@ -1180,6 +1233,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
 
     while (ok) {
+        PROF_T0();
         // ---- the 4096-position bitmap window that holds position p + 1 ------------
         int64_t pos = L.p + 1;
         if (pos < seg_start) pos = seg_start;
@@ -1208,11 +1262,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             L.p = (nxt - 1 < lim) ? nxt - 1 : lim;
             continue;
         }
+        PROF_ADD(MRZ_ST_T_WINDOW);
         int used = 0;
         const int64_t ev_before = L.n_events;
 #ifndef MRZ_NO_BATCH
         if (!prefer_seq) {
-            used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, width, lane, &ok, stat);
+            used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, width, lane, &ok, stat, mb, &mb_seq);
             epoch++;
             // adapt the width: shrink towards what could be committed, grow back when all of it was
             if (used >= width)
@@ -1224,6 +1279,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         }
 #endif
         prefer_seq = false;
+#ifdef MRZ_SEQ_PROFILE
+        prof_t0 = (int64_t)__builtin_amdgcn_s_memtime();  // the batch booked its own time
+#endif
         if (used == 0 && ok) {
             stat[MRZ_ST_SEQ] += 1;
             // first candidate of the window through the cooperative path
@@ -1233,8 +1291,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             const int64_t t = mrz_uni64(a.tags[L.p - seg_start]);
             if ((t & L.min_mask) == L.min_mask)  // src/rzip.c:573 with the mask reached by now
                 ok = mrz_seq_candidate(C, L, mb, &mb_seq, pend_h, pend_t, pend_o, t, lane);
+            PROF_ADD(MRZ_ST_T_SEQ);
         }
-        if (L.n_events != ev_before) prefer_seq = true;
+        (void)ev_before;
     }
 
     // release the helpers, then publish the state for the next segment's launch
