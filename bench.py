@@ -50,6 +50,17 @@ def cpu_baseline(sample_bytes):
             "matches": r["stats"]["matches"]}
 
 
+def pmc_traffic(nseg):
+    """HBM bytes per sequencer launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 +
+    WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes); None if no summary is present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["sequencer_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +153,7 @@ def main():
                        "level": args.level, "chunk_bytes_per_gpu": n, "streams": world},
             "roofline": {"bound": "hbm", "kernel": "mrz_sequencer_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": None,
+                         "traffic": pmc_traffic(nseg),
                          "launches_per_step": nseg, "alg_bytes_per_step": alg_bytes,
                          "avg_launch_ms": round(seq_ms / steps / max(nseg, 1), 4)},
             "kernel_ms_per_step": {"sequencer": round(seq_ms / steps, 2), "tagscan": round(tag_ms / steps, 2),

@@ -1,0 +1,92 @@
+"""CPU tier: the N>1 path over gloo with world_size 2 (the emulated library does
+the per-rank compute; what is under test is the sharding / chaining / gathering)."""
+import hashlib
+import os
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import modern_rzip_amd as m
+    from modern_rzip_amd import shard
+    from tests import _util
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = m.load_library(os.path.join(ROOT, "tests", "emu", "libmrzgpu_emu.so"))
+        oracle = _util.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+        # (1) independent streams: no collective on the data path
+        streams = [_util.rep64k(3, seed=40 + i, period=2048) for i in range(4)]
+        mine = shard.streams_of_rank(len(streams), rank, world)
+        digests = {}
+        for i in mine:
+            mrz, _, _ = m.rzip_buffer(streams[i], lib=lib)
+            digests[i] = hashlib.sha256(mrz).hexdigest()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, digests)
+        if rank == 0:
+            merged = {}
+            for g in gathered:
+                merged.update(g)
+            want = {i: hashlib.sha256(oracle.compress(s)[0]).hexdigest() for i, s in enumerate(streams)}
+            assert merged == want
+
+        # (2) one file, chunks dealt round-robin, victim_round chained rank to rank
+        data = _util.rep64k(10, seed=77, period=2048)
+        max_chunk = 8192  # page-rounded as src/rzip.c:888 requires: 3 chunks
+        ramsize = max_chunk // 2 * 3
+        ctx = m.RzipContext(lib=lib, max_chunk=max_chunk)
+
+        def run(chunk, vr_in):
+            ctx.victim_round = vr_in
+            res, s0, s1 = ctx.rzip_chunk(chunk)
+            return s0, s1, ctx.victim_round
+
+        parts = shard.rzip_file_chunk_chain(data, max_chunk, rank, world, run, dist)
+        ctx.close()
+        if rank == 0:
+            assert len(parts) == 3
+            md5 = hashlib.md5(data).digest()
+            got = oracle.frame(len(data), parts, md5, ramsize=ramsize)
+            want, _, _ = oracle.compress(data, ramsize=ramsize)
+            assert oracle.plan(len(data), ramsize=ramsize)[0] == max_chunk
+            assert got == want
+            rc, back = oracle.decompress(got)
+            assert rc == 0 and back == data
+        q.put((rank, "ok"))
+    except BaseException as e:  # surface the failure in the parent
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo(emu_lib, oracle):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def test_chunk_splitting_rules():
+    from modern_rzip_amd import shard
+    assert shard.split_chunks(0, 4096) == [(0, 0)]
+    assert shard.split_chunks(10, 4096) == [(0, 10)]
+    assert shard.split_chunks(8192, 4096) == [(0, 4096), (4096, 4096)]
+    assert shard.split_chunks(9000, 4096) == [(0, 4096), (4096, 4096), (8192, 808)]
+    assert shard.streams_of_rank(5, 1, 2) == [1, 3]
