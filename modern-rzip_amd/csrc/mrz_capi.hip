@@ -87,6 +87,7 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_crc_tables);
     hipFree(ctx->d_crc_parts);
     hipFree(ctx->d_crc_out);
+    if (ctx->d_gmailbox) hipFree(ctx->d_gmailbox);
     if (ctx->lz4_scratch) hipFree(ctx->lz4_scratch);
     if (ctx->b2_scratch) hipFree(ctx->b2_scratch);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
@@ -157,6 +158,13 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     }
     if (!rc && hipMemcpy(ctx->d_index, ctx->h_index, sizeof(ctx->h_index), hipMemcpyHostToDevice) != hipSuccess)
         rc = MRZ_E_HIP;
+    if (!rc && mrz_sequencer_mailbox_size() && !getenv("MRZ_NO_HELPER_WGS")) {
+        void *p = nullptr;
+        if (hipMalloc(&p, mrz_sequencer_mailbox_size()) != hipSuccess)
+            rc = MRZ_E_NOMEM;
+        else
+            ctx->d_gmailbox = p;
+    }
     if (!rc && max_chunk > 0) {
         rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, max_chunk / MRZ_MIN_MATCH + 2);
         if (!rc) rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(max_chunk));
@@ -324,7 +332,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         PROF_END();
         PROF_BEGIN(1);
         STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                  ctx->d_state, seg_start, seg_len));
+                                  ctx->d_state, seg_start, seg_len, ctx->d_gmailbox));
         PROF_END();
     }
     STEP(hipMemcpyAsync(&hs, ctx->d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
@@ -420,10 +428,12 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->hash_count = hs.count;
     res->n_events = E;
     if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[20] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
+        static const char *names[32] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
                                          "cut_cull", "batch_emits", "cut_cascade", "pairs", "formed", "t_form", "t_walk",
-                                         "t_walk2", "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window" };
-        for (int k = 0; k < 20; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
+                                         "t_walk2", "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window", "t_long",
+                                         "t_fold", "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait", "f_fold",
+                                         "f_helper_max" };
+        for (int k = 0; k < 32; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

@@ -43,6 +43,7 @@ struct mrz_ctx {
     uint32_t *d_crc_parts;
     int64_t crc_parts_cap;
     uint32_t *d_crc_out;
+    void *d_gmailbox;  // mailbox of the sequencer's helper workgroups
     int have_chunk;
 
     // LZ4 / BLAKE2b scratch (owned by their translation units, freed in mrz_close)

@@ -59,6 +59,13 @@
 #define PROF_ADD(k)
 #endif
 
+// diagnostics kept in mrz_seq_state.prof (always on, a handful of scalar adds)
+enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT,
+       MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED,
+       MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_WALK2, MRZ_ST_T_PAIRS, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_COMMIT,
+       MRZ_ST_T_SEQ, MRZ_ST_T_WINDOW, MRZ_ST_T_LONG, MRZ_ST_T_FOLD, MRZ_ST_FARMED, MRZ_ST_L_POST, MRZ_ST_L_STRIPE, MRZ_ST_L_BWD, MRZ_ST_L_WAIT,
+       MRZ_ST_L_ROUNDS, MRZ_ST_F_POST, MRZ_ST_F_WAIT, MRZ_ST_F_FOLD, MRZ_ST_F_HELPER, MRZ_ST_N };
+
 struct mrz_seq_args {
     const uint8_t *buf;
     mrz_slot *tab;
@@ -68,6 +75,7 @@ struct mrz_seq_args {
     mrz_seq_state *st;
     int64_t seg_start;
     int64_t seg_len;
+    void *gmailbox;           // mrz_gmailbox in device memory, zeroed by the host before every launch
 };
 
 // LDS mailbox between the leader and the helper waves: one long forward
@@ -166,8 +174,22 @@ __device__ static int64_t mrz_wave_bwd(const uint8_t *__restrict__ buf, int64_t 
 // workgroup (W x 4 KiB per round); the leader folds the per-wave results and does
 // the backward extension while the helpers are busy with the first round.
 __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int *mb_seq, int64_t p0,
-                                             int64_t op, int64_t end, int64_t last_match, int64_t *rev_out, int lane) {
+                                             int64_t op, int64_t end, int64_t last_match, int64_t *rev_out, int lane,
+                                             int64_t *stat = nullptr) {
     *rev_out = 0;
+#ifdef MRZ_SEQ_PROFILE
+    int64_t lt0 = (int64_t)__builtin_amdgcn_s_memtime();
+#define LPROF(k)                                                         \
+    do {                                                                 \
+        if (stat) {                                                      \
+            const int64_t now__ = (int64_t)__builtin_amdgcn_s_memtime(); \
+            stat[k] += now__ - lt0;                                      \
+            lt0 = now__;                                                 \
+        }                                                                \
+    } while (0)
+#else
+#define LPROF(k)
+#endif
     if (op >= p0) return 0;
     const int64_t maxf = end - p0;
     const int64_t floor_p = last_match > 0 ? last_match : 0;
@@ -188,15 +210,20 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
                 *mb_seq += 1;
                 if (lane == 0) mrz_mb_store(&mb->seq, *mb_seq);
             }
+            LPROF(MRZ_ST_L_POST);
             int64_t best = mrz_wave_fwd_stripe(buf, p0, op, maxf, base, lane);  // the leader's own stripe (wave 0)
+            LPROF(MRZ_ST_L_STRIPE);
             if (!have_rev) {
                 rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
                 have_rev = true;
             }
+            LPROF(MRZ_ST_L_BWD);
             if (MRZ_SEQ_WAVES > 1) {
                 while (mrz_uni(mrz_mb_load(&mb->done)) < MRZ_SEQ_WAVES - 1) __builtin_amdgcn_s_sleep(1);
                 for (int w = 1; w < MRZ_SEQ_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
             }
+            LPROF(MRZ_ST_L_WAIT);
+            if (stat) stat[MRZ_ST_L_ROUNDS] += 1;
             if (best >= 0) {
                 fwd = best;
                 break;
@@ -347,6 +374,120 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
     }
 }
 
+// ---- helper workgroups on other CUs ------------------------------------------------------
+// A look-up on repetitive input can find max_chain_len tag-equal entries that are ALL tens of
+// KiB long (every earlier copy of the same text): ~1 MB to compare for one candidate, which is
+// what one CU can pull through its L1/L2 in ~15 us.  The compares are independent, so the grid
+// carries MRZ_HELPER_WGS extra workgroups (one per CU: 512 threads x 256 VGPRs fill a CU) that
+// wait on a mailbox in device memory; the leader hands each of them one entry.
+// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms"): every handed-off word is written with
+// an agent-scope atomic store (write-through, sc1) and read with an agent-scope atomic load
+// (sc1); every storing wave drains (s_waitcnt vmcnt(0)) before the flag / counter update; flags
+// are polled with relaxed agent-scope loads and s_sleep.  The compared bytes themselves are
+// read-only input.  All spins are bounded.
+#ifndef MRZ_HELPER_WGS
+#define MRZ_HELPER_WGS 16
+#endif
+#define MRZ_SPIN_LIMIT (1 << 22)          // leader: ~1 s of polling for an answer that takes microseconds
+#define MRZ_HELPER_SPIN_LIMIT (1ll << 34)  // helpers: idle for as long as a launch may run
+
+struct mrz_gmailbox {
+    unsigned long long seq;          // bumped by the leader per job round
+    unsigned long long quit;
+    unsigned long long done;         // helpers add 1 per finished job
+    unsigned long long njobs;
+    long long p0, maxf, maxb_floor;  // compare buf[p0+x] / buf[op+x], x < maxf; backward floor = max(0,last_match)
+    long long pad0;
+    long long op[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
+    long long fwd[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
+    long long rev[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
+    long long dbg[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];  // helper busy time of the last job (profile builds)
+};
+
+__device__ __forceinline__ long long mrz_g_load(const long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long mrz_g_loadu(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mrz_g_store(long long *p, long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mrz_g_storeu(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mrz_drain_stores() {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+#if MRZ_HELPER_WGS > 0
+// one helper workgroup: job index = blockIdx.x - 1
+__device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailbox *g) {
+    __shared__ long long s_job[4];           // seq, quit
+    __shared__ long long s_res[MRZ_SEQ_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = mrz_uni((int)(threadIdx.x >> 6));
+    const int me = (int)blockIdx.x - 1;
+    unsigned long long seen = 0;
+    while (true) {
+        if (threadIdx.x == 0) {
+            unsigned long long s = seen;
+            long long spins = 0;
+            while ((s = mrz_g_loadu(&g->seq)) == seen && spins++ < MRZ_HELPER_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+            s_job[0] = (long long)s;
+            s_job[1] = (s == seen) ? 1 : (long long)mrz_g_loadu(&g->quit);  // spin limit => give up
+        }
+        __syncthreads();
+        const unsigned long long s = (unsigned long long)s_job[0];
+        const bool quit = s_job[1] != 0;
+        __syncthreads();
+        if (quit) return;
+        seen = s;
+#ifdef MRZ_SEQ_PROFILE
+        const long long h_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        const int nj = (int)mrz_g_loadu(&g->njobs);
+        if (me >= nj) continue;
+        const int64_t p0 = mrz_g_load(&g->p0), maxf = mrz_g_load(&g->maxf), floor_p = mrz_g_load(&g->maxb_floor);
+        const int64_t op = mrz_g_load(&g->op[me]);
+        int64_t fwd = 0;
+        if (op < p0 && maxf > 0) {
+            for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * MRZ_STRIPE) {
+                const int64_t r = mrz_wave_fwd_stripe(buf, p0, op, maxf, base + (int64_t)wave * MRZ_STRIPE, lane);
+                if (lane == 0) s_res[wave] = r;
+                __syncthreads();
+                int64_t best = -1;
+                for (int w = 0; w < MRZ_SEQ_WAVES && best < 0; w++) best = s_res[w];
+                __syncthreads();
+                if (best >= 0) {
+                    fwd = best;
+                    break;
+                }
+            }
+        }
+        if (wave == 0) {
+            int64_t rev = 0;
+            if (op < p0) {
+                int64_t maxb = p0 - floor_p;
+                if (op < maxb) maxb = op;
+                rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
+            }
+            if (lane == 0) {
+                mrz_g_store(&g->fwd[me], op < p0 ? fwd : -1);
+                mrz_g_store(&g->rev[me], rev);
+#ifdef MRZ_SEQ_PROFILE
+                mrz_g_store(&g->dbg[me], (long long)__builtin_amdgcn_s_memtime() - h_t0);
+#endif
+                mrz_drain_stores();
+                __hip_atomic_fetch_add(&g->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+#endif
+
 // ---- leader state ----------------------------------------------------------------
 struct mrz_lead {  // wave-uniform; what hash_search keeps in locals / rzip_state
     int64_t p, cur_p, cur_ofs, cur_len, last_match;
@@ -360,6 +501,8 @@ struct mrz_cfg {
     mrz_event *events;
     mrz_seq_state *st;
     int64_t end, limit, max_chain, slot_mask, nslots, event_cap;
+    mrz_gmailbox *gmb;
+    unsigned long long *gseq;  // leader's copy of the global round counter
 };
 
 // lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
@@ -590,11 +733,7 @@ struct mrz_batch_lds {
     unsigned filter[MRZ_FILTER_SIZE];
 };
 
-// diagnostics kept in mrz_seq_state.prof (always on, a handful of scalar adds)
-enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT,
-       MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED,
-       MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_WALK2, MRZ_ST_T_PAIRS, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_COMMIT,
-       MRZ_ST_T_SEQ, MRZ_ST_T_WINDOW, MRZ_ST_N };
+
 
 #ifdef __HIP_DEVICE_COMPILE__
 #define MRZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
@@ -1041,12 +1180,88 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         const int64_t qx = mrz_bcast64(q, x);
         int64_t xb = 0, xoff = 0, xrev = 0;
         int xh = 0, xm = 0;
-        for (int k = 0; k < nsx; k++) {
+        bool farmed = false;
+#if MRZ_HELPER_WGS > 0
+        {
+            // hand every long entry of this lane to its own helper workgroup
+            int nlong = 0;
+            for (int k = 0; k < nsx; k++)
+                if (mrz_uni(B->pair_res[x][k]) < 0) nlong++;
+            if (nlong >= 2 && nsx <= MRZ_HELPER_WGS && C.gmb) {
+                mrz_gmailbox *g = C.gmb;
+                if (lane < nsx) {
+                    // entries that are not long get an offset >= p0, which a helper answers with -1 at once
+                    const bool is_long = B->pair_res[x][lane] < 0;
+                    mrz_g_store(&g->op[lane], is_long ? (long long)B->same_off[x][lane] : (long long)qx);
+                }
+                if (lane == 0) {
+                    const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
+                    mrz_g_store(&g->p0, qx);
+                    mrz_g_store(&g->maxf, C.end - qx);
+                    mrz_g_store(&g->maxb_floor, floor_p);
+                    mrz_g_storeu(&g->njobs, (unsigned long long)nsx);
+                    mrz_g_storeu(&g->done, 0ull);
+                }
+                mrz_drain_stores();
+                *C.gseq += 1;
+                if (lane == 0) mrz_g_storeu(&g->seq, *C.gseq);
+                PROF_ADD(MRZ_ST_F_POST);
+                int spins = 0;
+                bool arrived = false;
+                while (!arrived && spins++ < MRZ_SPIN_LIMIT) {
+                    arrived = mrz_uni((int)mrz_g_loadu(&g->done)) >= nsx;
+                    if (!arrived) __builtin_amdgcn_s_sleep(2);
+                }
+                if (!arrived) {
+                    if (lane == 0) C.st->error = 3;  // helpers never answered
+                    *ok = false;
+                    return 0;
+                }
+                farmed = true;
+                stat[MRZ_ST_FARMED] += 1;
+                PROF_ADD(MRZ_ST_F_WAIT);
+#ifdef MRZ_SEQ_PROFILE
+                {
+                    long long hmax = 0;
+                    for (int k = 0; k < nsx; k++) {
+                        const long long hv = mrz_uni64(mrz_g_load(&g->dbg[k]));
+                        if (mrz_uni(B->pair_res[x][k]) < 0 && hv > hmax) hmax = hv;
+                    }
+                    stat[MRZ_ST_F_HELPER] += hmax;
+                }
+#endif
+                for (int k = 0; k < nsx; k++) {
+                    const int r = mrz_uni(B->pair_res[x][k]);
+                    const int64_t op = mrz_uni64(B->same_off[x][k]);
+                    int64_t ml, rv;
+                    if (r < 0) {
+                        const int64_t fw = mrz_uni64(mrz_g_load(&g->fwd[k]));
+                        rv = mrz_uni64(mrz_g_load(&g->rev[k]));
+                        ml = fw + rv;
+                        if (fw < 0 || ml < MRZ_MIN_MATCH) ml = 0;
+                    } else {
+                        ml = r >> 8;
+                        rv = r & 0xff;
+                    }
+                    if (ml) {  // first longest wins, :446-450
+                        if (ml > xb) {
+                            xb = ml;
+                            xoff = op - rv;
+                            xrev = rv;
+                        }
+                        xh++;
+                    } else
+                        xm++;
+                }
+            }
+        }
+#endif
+        for (int k = 0; k < nsx && !farmed; k++) {
             const int r = mrz_uni(B->pair_res[x][k]);
             const int64_t op = mrz_uni64(B->same_off[x][k]);
             int64_t ml, rv;
             if (r < 0)
-                ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane);
+                ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat);
             else {
                 ml = r >> 8;
                 rv = r & 0xff;
@@ -1061,6 +1276,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
             } else
                 xm++;
         }
+        PROF_ADD(MRZ_ST_T_LONG);
         if (lane == x) {
             best = xb;
             best_off = xoff;
@@ -1114,6 +1330,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         n_ok = emit_lane + 1;
         stat[MRZ_ST_BATCH_EMITS] += 1;
     }
+    PROF_ADD(MRZ_ST_T_FOLD);
     stat[MRZ_ST_BATCHES] += 1;
     stat[MRZ_ST_BATCH_LANES] += n_ok;
     const mrz_u64 keep = mrz_low_mask(n_ok);
@@ -1178,6 +1395,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     mrz_mailbox *mb = &mbox;
 
     if (st->finished || st->error) return;
+#if MRZ_HELPER_WGS > 0
+    if (blockIdx.x != 0) {
+        mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
+        return;
+    }
+#endif
     if (threadIdx.x == 0) {
         mb->seq = 0;
         mb->done = 0;
@@ -1201,6 +1424,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     C.slot_mask = st->slot_mask;
     C.nslots = st->slot_mask + 1;
     C.event_cap = st->event_cap;
+    C.gmb = (mrz_gmailbox *)a.gmailbox;
+    unsigned long long gseq = 0;
+    C.gseq = &gseq;
     mrz_lead L;
     L.p = st->p;
     L.cur_p = st->cur_p;
@@ -1297,6 +1523,13 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     }
 
     // release the helpers, then publish the state for the next segment's launch
+#if MRZ_HELPER_WGS > 0
+    if (lane == 0 && C.gmb) {
+        mrz_g_storeu(&C.gmb->quit, 1ull);
+        mrz_drain_stores();
+        mrz_g_storeu(&C.gmb->seq, gseq + 1);
+    }
+#endif
     if (lane == 0) {
         mrz_mb_store(&mb->quit, 1);
         mrz_mb_store(&mb->seq, mb_seq + 1);
@@ -1321,7 +1554,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 
 extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
                                            const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
-                                           int64_t seg_start, int64_t seg_len) {
+                                           int64_t seg_start, int64_t seg_len, void *gmailbox) {
     mrz_seq_args a;
     a.buf = buf;
     a.tab = tab;
@@ -1331,6 +1564,14 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     a.st = st;
     a.seg_start = seg_start;
     a.seg_len = seg_len;
-    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1), dim3(MRZ_SEQ_THREADS), 0, stream, a);
+    a.gmailbox = gmailbox;
+    if (gmailbox) {
+        hipError_t e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1 + (gmailbox ? MRZ_HELPER_WGS : 0)), dim3(MRZ_SEQ_THREADS), 0, stream,
+                       a);
     return hipGetLastError();
 }
+
+extern "C" size_t mrz_sequencer_mailbox_size(void) { return MRZ_HELPER_WGS > 0 ? sizeof(mrz_gmailbox) : 0; }
