@@ -39,11 +39,28 @@
 // extension -- not HBM bandwidth.
 #include "mrz_device.h"
 
+// cross-lane LDS exchange inside one wave: the hardware runs the lanes in lockstep, the CPU
+// emulator needs a rendezvous
+#ifdef __HIP_DEVICE_COMPILE__
+#define MRZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define MRZ_WAVE_SYNC() (void)__ballot(1)
+#endif
+
 #ifndef MRZ_SEQ_WAVES
 #define MRZ_SEQ_WAVES 8  // 512 threads: 256 VGPRs per lane, no spills in the batch engine
 #endif
 #define MRZ_SEQ_THREADS (64 * MRZ_SEQ_WAVES)
+// wave 0 = leader, waves 1..MRZ_STRIPE_WAVES-1 = striping helpers, last wave = scout (prefetcher)
+#define MRZ_STRIPE_WAVES (MRZ_SEQ_WAVES > 2 ? MRZ_SEQ_WAVES - 1 : MRZ_SEQ_WAVES)
+#define MRZ_HAVE_SCOUT (MRZ_SEQ_WAVES > 2)
 #define MRZ_CASCADE_MAX 64
+#ifndef MRZ_SEQ_CREDIT
+#define MRZ_SEQ_CREDIT 16      // candidates sent through the cooperative path after repeated tiny batches
+#endif
+#ifndef MRZ_LOW_YIELD_RUNS
+#define MRZ_LOW_YIELD_RUNS 3
+#endif
 
 // optional in-kernel cycle accounting (diagnostic builds only: -DMRZ_SEQ_PROFILE)
 #ifdef MRZ_SEQ_PROFILE
@@ -86,7 +103,9 @@ struct mrz_mailbox {
     int seq;                        // bumped by the leader for every round; helpers wait on it
     int done;                       // helpers add 1 when their stripe is finished
     int quit;
-    int pad;
+    int scout_seq;                  // bumped whenever scout_pos changes
+    int64_t scout_pos;              // the leader's position: the scout warms the caches for what follows
+    int64_t scout_clean;            // tag_clean_ptr, for the cull sweep window
 };
 
 // workgroup-scope accesses to the mailbox words
@@ -107,11 +126,12 @@ __device__ __forceinline__ void mrz_mb_add(int *p, int v) {
 // pieces, all loads issued before the first compare).  Returns the offset (from
 // p0) at which `while (p < end && buf[p] == buf[op])` (src/rzip.c:378) stops if
 // that lies inside or before this stripe's reach, else -1.
-__device__ static int64_t mrz_wave_fwd_stripe(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, int64_t maxf,
-                                              int64_t base, int lane) {
-    uint4 a[MRZ_STRIPE_PIECES], b[MRZ_STRIPE_PIECES];
+template <int PIECES>
+__device__ static int64_t mrz_wave_fwd_stripe_n(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, int64_t maxf,
+                                                int64_t base, int lane) {
+    uint4 a[PIECES], b[PIECES];
 #pragma unroll
-    for (int j = 0; j < MRZ_STRIPE_PIECES; j++) {
+    for (int j = 0; j < PIECES; j++) {
         const int64_t off = base + j * 1024 + lane * 16;
         if (off < maxf) {
             a[j] = mrz_ld16(buf + p0 + off);
@@ -120,7 +140,7 @@ __device__ static int64_t mrz_wave_fwd_stripe(const uint8_t *__restrict__ buf, i
     }
     int64_t found = -1;
 #pragma unroll
-    for (int j = 0; j < MRZ_STRIPE_PIECES; j++) {
+    for (int j = 0; j < PIECES; j++) {
         if (found >= 0) continue;
         const int64_t off = base + j * 1024 + lane * 16;
         int lane_len = 0;
@@ -139,6 +159,11 @@ __device__ static int64_t mrz_wave_fwd_stripe(const uint8_t *__restrict__ buf, i
         }
     }
     return found;
+}
+
+__device__ __forceinline__ int64_t mrz_wave_fwd_stripe(const uint8_t *__restrict__ buf, int64_t p0, int64_t op,
+                                                       int64_t maxf, int64_t base, int lane) {
+    return mrz_wave_fwd_stripe_n<MRZ_STRIPE_PIECES>(buf, p0, op, maxf, base, lane);
 }
 
 // Backward half of single_match_len (src/rzip.c:386-391), wave-wide.
@@ -198,8 +223,8 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
     int64_t fwd = 0, rev = 0;
     bool have_rev = false;
     if (maxf > 0) {
-        for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * MRZ_STRIPE) {
-            if (MRZ_SEQ_WAVES > 1) {
+        for (int64_t base = 0;; base += (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE) {
+            if (MRZ_STRIPE_WAVES > 1) {
                 if (lane == 0) {
                     mb->p0 = p0;
                     mb->op = op;
@@ -218,9 +243,9 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
                 have_rev = true;
             }
             LPROF(MRZ_ST_L_BWD);
-            if (MRZ_SEQ_WAVES > 1) {
-                while (mrz_uni(mrz_mb_load(&mb->done)) < MRZ_SEQ_WAVES - 1) __builtin_amdgcn_s_sleep(1);
-                for (int w = 1; w < MRZ_SEQ_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
+            if (MRZ_STRIPE_WAVES > 1) {
+                while (mrz_uni(mrz_mb_load(&mb->done)) < MRZ_STRIPE_WAVES - 1) __builtin_amdgcn_s_sleep(1);
+                for (int w = 1; w < MRZ_STRIPE_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
             }
             LPROF(MRZ_ST_L_WAIT);
             if (stat) stat[MRZ_ST_L_ROUNDS] += 1;
@@ -356,6 +381,82 @@ __device__ __forceinline__ bool mrz_insert_step(const mrz_slot e, bool empty, in
     return false;
 }
 
+// The scout (last wave of the leader's workgroup) never decides anything: it reads the
+// leader's published position and pulls into this CU's L1 / this XCD's L2 what the leader
+// will need next -- the tags of the following 128 candidates, the first table line of each
+// of their probe chains, the bytes at the offsets of tag-equal entries, and the cull sweep
+// window -- so that the leader's dependent loads hit cache instead of HBM.
+struct mrz_scout_args {
+    const uint8_t *buf;
+    const mrz_slot *tab;
+    const int64_t *tags;
+    const mrz_u64 *bitmap;
+    int64_t seg_start, lim, nwords, slot_mask, nslots;
+};
+
+__device__ static void mrz_scout_loop(const mrz_scout_args &S, mrz_mailbox *mb, int lane) {
+    __shared__ int sc_pref[64];
+    __shared__ mrz_u64 sc_word[64];
+    int seen = 0;
+    unsigned sink = 0;
+    while (true) {
+        int s;
+        while ((s = mrz_uni(mrz_mb_load(&mb->scout_seq))) == seen) {
+            if (mrz_uni(mrz_mb_load(&mb->quit))) {
+                if (sink == 0x9e3779b9u) sc_pref[0] = (int)sink;  // keeps the prefetch loads alive
+                return;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        seen = s;
+        const int64_t pos = mrz_uni64(mb->scout_pos) + 1;
+        if (pos > S.lim) continue;
+        // cull sweep window
+        const int64_t cp = mrz_uni64(mb->scout_clean);
+        if (cp + lane * 4 < S.nslots) sink += (unsigned)S.tab[cp + lane * 4].off;  // 4 KiB ahead of the sweep
+        const int64_t wb = S.seg_start + ((pos - S.seg_start) >> 12 << 12);
+        const int64_t idx = ((wb - S.seg_start) >> 6) + lane;
+        mrz_u64 w = idx < S.nwords ? S.bitmap[idx] : 0ull;
+        const int64_t lane_lo = wb + (int64_t)lane * 64;
+        if (pos > lane_lo) {
+            const int64_t sh = pos - lane_lo;
+            w = sh >= 64 ? 0ull : (w >> sh) << sh;
+        }
+        const int cnt = __popcll(w);
+        const int incl = mrz_wave_incl_sum(cnt, lane);
+        const int total = mrz_lane_read(incl, 63);
+        sc_pref[lane] = incl - cnt;
+        sc_word[lane] = w;
+        MRZ_WAVE_SYNC();
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int r = half * 64 + lane;
+            if (r < total) {
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sc_pref[mid] <= r)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                const int64_t qq = wb + (int64_t)lo * 64 + mrz_select64(sc_word[lo], r - sc_pref[lo]);
+                if (qq <= S.lim) {
+                    const int64_t t = S.tags[qq - S.seg_start];
+                    const int64_t h = t & S.slot_mask;
+                    const mrz_slot e0 = S.tab[h];
+                    const mrz_slot e1 = S.tab[(h + 7) & S.slot_mask];  // the line may straddle
+                    sink += (unsigned)e0.off + (unsigned)e1.off;
+                    if (e0.t == t && e0.off > 0) sink += S.buf[e0.off];
+                    sink += S.buf[qq];
+                }
+            }
+        }
+        MRZ_WAVE_SYNC();
+    }
+}
+
 // helper waves: serve striped forward-extension rounds until the leader says quit
 __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int wave, int lane) {
     int seen = 0;
@@ -454,8 +555,9 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
         const int64_t op = mrz_g_load(&g->op[me]);
         int64_t fwd = 0;
         if (op < p0 && maxf > 0) {
-            for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * MRZ_STRIPE) {
-                const int64_t r = mrz_wave_fwd_stripe(buf, p0, op, maxf, base + (int64_t)wave * MRZ_STRIPE, lane);
+            // 8 KiB per wave and round: a 64 KiB match is one round of the workgroup
+            for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * 8192) {
+                const int64_t r = mrz_wave_fwd_stripe_n<8>(buf, p0, op, maxf, base + (int64_t)wave * 8192, lane);
                 if (lane == 0) s_res[wave] = r;
                 __syncthreads();
                 int64_t best = -1;
@@ -488,235 +590,7 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
 }
 #endif
 
-// ---- leader state ----------------------------------------------------------------
-struct mrz_lead {  // wave-uniform; what hash_search keeps in locals / rzip_state
-    int64_t p, cur_p, cur_ofs, cur_len, last_match;
-    int64_t min_mask, tag_mask, count, clean_ptr, victim_round;
-    int64_t n_events, inserts, tag_hits, tag_misses;
-};
-
-struct mrz_cfg {
-    const uint8_t *buf;
-    mrz_slot *tab;
-    mrz_event *events;
-    mrz_seq_state *st;
-    int64_t end, limit, max_chain, slot_mask, nslots, event_cap;
-    mrz_gmailbox *gmb;
-    unsigned long long *gseq;  // leader's copy of the global round counter
-};
-
-// lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
-// look-up returned (mlen, m_off, m_rev).  Returns false on event-list overflow.
-__device__ __forceinline__ bool mrz_select_emit(const mrz_cfg &C, mrz_lead &L, int64_t mlen, int64_t m_off,
-                                                int64_t m_rev, int lane) {
-    if (mlen > L.cur_len) {
-        L.cur_p = L.p - m_rev;
-        L.cur_len = mlen;
-        L.cur_ofs = m_off;
-    }
-    if ((L.cur_len >= MRZ_GREAT_MATCH || L.p >= L.cur_p + MRZ_MIN_MATCH) && L.cur_len >= MRZ_MIN_MATCH) {
-        if (L.n_events >= C.event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
-            if (lane == 0) C.st->error = 1;
-            return false;
-        }
-        if (lane == 0) {
-            mrz_event ev;
-            ev.p = L.cur_p;
-            ev.ofs = L.cur_ofs;
-            ev.len = L.cur_len;
-            C.events[L.n_events] = ev;
-        }
-        L.n_events++;
-        L.last_match = L.cur_p + L.cur_len;
-        L.cur_p = L.p = L.last_match;
-        L.cur_len = 0;
-    }
-    return true;
-}
-
-// clean_one_from_hash (src/rzip.c:305-328), 64 slots per sweep step
-__device__ static void mrz_cull_one(const mrz_cfg &C, mrz_lead &L, int lane) {
-    mrz_slot *tab = C.tab;
-    while (true) {
-        const int64_t better2 = (L.min_mask << 1) | 1;
-        bool culled = false;
-        while (L.clean_ptr < C.nslots) {
-            const int64_t s = L.clean_ptr + lane;
-            mrz_slot e;
-            e.off = 0;
-            e.t = 0;
-            if (s < C.nslots) e = tab[s];
-            const bool hit = ((e.off | e.t) != 0) && ((e.t & better2) != better2);
-            const mrz_u64 m = __ballot(hit);
-            if (m) {
-                const int fl = __ffsll((long long)m) - 1;
-                L.clean_ptr += fl;
-                if (lane == fl) {
-                    mrz_slot z;
-                    z.off = 0;
-                    z.t = 0;
-                    tab[s] = z;
-                }
-                L.count--;
-                culled = true;
-                break;
-            }
-            L.clean_ptr += MRZ_WAVE;
-        }
-        if (culled) {
-            L.tag_mask = better2;
-            return;
-        }
-        L.min_mask = better2;
-        L.clean_ptr = 0;
-    }
-}
-
-// One candidate, fully in order: the wave-cooperative path (any chain length,
-// any match length, cascades, chain-limit evictions, mask promotion).
-__device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_mailbox *mb, int *mb_seq, int64_t *pend_h,
-                                         int64_t *pend_t, int64_t *pend_o, int64_t t, int lane) {
-    const uint8_t *__restrict__ buf = C.buf;
-    mrz_slot *tab = C.tab;
-    const int64_t p = L.p, end = C.end, slot_mask = C.slot_mask, max_chain = C.max_chain;
-    // ---- one pass over the chain: find_best_match (:426-462) and, when this
-    // position is inserted (:579), the probe walk of insert_hash ----------
-    const bool do_insert = (t & L.tag_mask) == L.tag_mask;
-    const int64_t better = (L.min_mask << 1) | 1;
-    const int my_rank = mrz_ones_rank(t);
-    int64_t mlen = 0, m_off = 0, m_rev = 0;
-    bool ins_found = !do_insert;
-    int64_t ins_slot = 0, occ_t = 0, occ_off = 0;
-    int ins_kind = 0;
-    if (do_insert) {
-        L.inserts++;
-        L.count++;
-    }
-    {
-        const int64_t h0 = t & slot_mask;
-        int64_t round = 0, victim_h = 0;
-        for (int64_t b = 0;; b += MRZ_WAVE) {
-            const int64_t s = (h0 + b + lane) & slot_mask;
-            const mrz_slot e = tab[s];
-            const bool empty = (e.off | e.t) == 0;
-            const mrz_u64 m_empty = __ballot(empty);
-            const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : MRZ_WAVE;
-            if (!ins_found)
-                ins_found = mrz_insert_step(e, empty, t, my_rank, h0 + b, slot_mask, better, max_chain, &round,
-                                            &victim_h, &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t,
-                                            &occ_off);
-            const mrz_u64 m_same = __ballot(!empty && e.t == t) & mrz_low_mask(first_empty);
-            if (m_same) {
-                // tag-equal entries of this step, probe order, 8 per pass
-                mrz_u64 todo = m_same;
-                while (todo) {
-                    const int g = lane >> 3;  // the g-th remaining entry goes to lane group g
-                    mrz_u64 tmp = todo;
-                    int src_lane = -1, npass = 0;
-                    for (int k = 0; k < 8 && tmp; k++) {
-                        const int sl = __ffsll((long long)tmp) - 1;
-                        tmp &= tmp - 1;
-                        if (k == g) src_lane = sl;
-                        npass++;
-                    }
-                    const bool valid = src_lane >= 0;
-                    const int rd = valid ? src_lane : 0;
-                    const int lo = __shfl((int)(uint32_t)(uint64_t)e.off, rd, MRZ_WAVE);
-                    const int hi = __shfl((int)(uint32_t)((uint64_t)e.off >> 32), rd, MRZ_WAVE);
-                    const int64_t op = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-                    int64_t g_len, g_rev;
-                    bool g_long;
-                    mrz_short_match_len(buf, p, op, valid, end, L.last_match, lane, &g_len, &g_rev, &g_long);
-                    for (int k = 0; k < npass; k++) {
-                        int64_t ml = mrz_bcast64(g_len, 8 * k);
-                        int64_t rv = mrz_bcast64(g_rev, 8 * k);
-                        const int64_t opk = mrz_bcast64(op, 8 * k);
-                        if (mrz_lane_read(g_long ? 1 : 0, 8 * k))
-                            ml = mrz_long_match_len(buf, mb, mb_seq, p, opk, end, L.last_match, &rv, lane);
-                        if (ml) {  // first longest wins, :446-450
-                            if (ml > mlen) {
-                                mlen = ml;
-                                m_off = opk - rv;
-                                m_rev = rv;
-                            }
-                            L.tag_hits++;
-                        } else
-                            L.tag_misses++;
-                    }
-                    todo = tmp;
-                }
-            }
-            if (first_empty < MRZ_WAVE) break;
-        }
-    }
-
-    // ---- insert + cull (:579-584) -------------------------------------
-    if (do_insert) {
-        int np = 0;
-        int64_t it = t, io = p;
-        while (true) {
-            if (np >= MRZ_CASCADE_MAX) {  // cannot happen: every level has a strictly lower rank
-                if (lane == 0) C.st->error = 2;
-                return false;
-            }
-            if (lane == 0) {
-                pend_h[np] = ins_slot;
-                pend_t[np] = it;
-                pend_o[np] = io;
-            }
-            np++;
-            if (ins_kind != 2) break;
-            // re-insert the displaced occupant: its own probe walk
-            it = occ_t;
-            io = occ_off;
-            const int64_t h0 = it & slot_mask;
-            const int rank2 = mrz_ones_rank(it);
-            int64_t round = 0, victim_h = 0;
-            for (int64_t b = 0;; b += MRZ_WAVE) {
-                const int64_t s = (h0 + b + lane) & slot_mask;
-                const mrz_slot e = tab[s];
-                const bool empty = (e.off | e.t) == 0;
-                if (mrz_insert_step(e, empty, it, rank2, h0 + b, slot_mask, better, max_chain, &round, &victim_h,
-                                    &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t, &occ_off))
-                    break;
-            }
-        }
-        // write back innermost-first (the recursion's return order)
-        while (np-- > 0) {
-            const int64_t hs = mrz_uni64(pend_h[np]);
-            if (lane == 0) {
-                mrz_slot w;
-                w.off = pend_o[np];
-                w.t = pend_t[np];
-                tab[hs] = w;
-            }
-        }
-        if (L.count > C.limit) mrz_cull_one(C, L, lane);
-    }
-    return mrz_select_emit(C, L, mlen, m_off, m_rev, lane);
-}
-
-// ---- the batch engine -------------------------------------------------------------
-// Up to 64 consecutive candidates are processed at once, ONE LANE PER CANDIDATE,
-// against the table as it stands at the start of the batch:
-//   1. every lane walks its own probe chain (4 slots = 64 B per step) and records
-//      first-empty, the tag-equal entries, and where insert_hash's walk stops
-//      (empty / due-for-culling overwrite / lower-ranked occupant to displace / the
-//      max_chain_len-th tag-equal entry => victim eviction);
-//   1b. lanes that displace an occupant walk that occupant's chain too;
-//   2. every lane extends its tag-equal candidates itself, 64 B each way;
-//   3. wave scans turn the per-lane facts into the sequential quantities:
-//      victim_round per evicting lane (prefix count), hash_count before each lane
-//      (saturating prefix sum), which lanes cull and which sweep entry each culls
-//      (rank into the ballot of failing entries ahead of tag_clean_ptr);
-//   4. a lane may only be committed if no EARLIER lane's write (insert, displaced
-//      re-insert, cull) falls inside the slots it read: an LDS filter keyed by
-//      64-slot block flags suspects, suspects are checked exactly.  The batch is
-//      cut at the first lane that conflicts or needs the cooperative path
-//      (long match, long chain, deep cascade, sweep wrap, mask transition), the
-//      lazy-match fold (:586-599) may cut it earlier at an emission;
-//   5. all surviving lanes write their slots in one go.
-// The committed prefix is exactly what the reference's loop would have done.
+// ---- definitions shared by the batch engine and the cooperative path ---------------------
 #define MRZ_SMAX 16
 #define MRZ_WALK_SLOTS 8   // slots (16 B each) a lane loads per walk step: one 128-B line when aligned
 #define MRZ_WALK_STEPS 12
@@ -735,11 +609,6 @@ struct mrz_batch_lds {
 
 
 
-#ifdef __HIP_DEVICE_COMPILE__
-#define MRZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#else
-#define MRZ_WAVE_SYNC() (void)__ballot(1)
-#endif
 
 __device__ __forceinline__ unsigned mrz_filter_slot(int slot) {
     return ((unsigned)(slot >> 6) * 2654435761u) >> 20;  // 12 bits
@@ -835,6 +704,324 @@ __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64
     *len = l >= MRZ_MIN_MATCH ? l : 0;
 }
 
+
+// ---- leader state ----------------------------------------------------------------
+struct mrz_lead {  // wave-uniform; what hash_search keeps in locals / rzip_state
+    int64_t p, cur_p, cur_ofs, cur_len, last_match;
+    int64_t min_mask, tag_mask, count, clean_ptr, victim_round;
+    int64_t n_events, inserts, tag_hits, tag_misses;
+};
+
+struct mrz_cfg {
+    const uint8_t *buf;
+    mrz_slot *tab;
+    mrz_event *events;
+    mrz_seq_state *st;
+    int64_t end, limit, max_chain, slot_mask, nslots, event_cap;
+    mrz_gmailbox *gmb;
+    unsigned long long *gseq;  // leader's copy of the global round counter
+};
+
+// lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
+// look-up returned (mlen, m_off, m_rev).  Returns false on event-list overflow.
+__device__ __forceinline__ bool mrz_select_emit(const mrz_cfg &C, mrz_lead &L, int64_t mlen, int64_t m_off,
+                                                int64_t m_rev, int lane) {
+    if (mlen > L.cur_len) {
+        L.cur_p = L.p - m_rev;
+        L.cur_len = mlen;
+        L.cur_ofs = m_off;
+    }
+    if ((L.cur_len >= MRZ_GREAT_MATCH || L.p >= L.cur_p + MRZ_MIN_MATCH) && L.cur_len >= MRZ_MIN_MATCH) {
+        if (L.n_events >= C.event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
+            if (lane == 0) C.st->error = 1;
+            return false;
+        }
+        if (lane == 0) {
+            mrz_event ev;
+            ev.p = L.cur_p;
+            ev.ofs = L.cur_ofs;
+            ev.len = L.cur_len;
+            C.events[L.n_events] = ev;
+        }
+        L.n_events++;
+        L.last_match = L.cur_p + L.cur_len;
+        L.cur_p = L.p = L.last_match;
+        L.cur_len = 0;
+    }
+    return true;
+}
+
+// clean_one_from_hash (src/rzip.c:305-328), 64 slots per sweep step
+__device__ static void mrz_cull_one(const mrz_cfg &C, mrz_lead &L, int lane) {
+    mrz_slot *tab = C.tab;
+    while (true) {
+        const int64_t better2 = (L.min_mask << 1) | 1;
+        bool culled = false;
+        while (L.clean_ptr < C.nslots) {
+            const int64_t s = L.clean_ptr + lane;
+            mrz_slot e;
+            e.off = 0;
+            e.t = 0;
+            if (s < C.nslots) e = tab[s];
+            const bool hit = ((e.off | e.t) != 0) && ((e.t & better2) != better2);
+            const mrz_u64 m = __ballot(hit);
+            if (m) {
+                const int fl = __ffsll((long long)m) - 1;
+                L.clean_ptr += fl;
+                if (lane == fl) {
+                    mrz_slot z;
+                    z.off = 0;
+                    z.t = 0;
+                    tab[s] = z;
+                }
+                L.count--;
+                culled = true;
+                break;
+            }
+            L.clean_ptr += MRZ_WAVE;
+        }
+        if (culled) {
+            L.tag_mask = better2;
+            return;
+        }
+        L.min_mask = better2;
+        L.clean_ptr = 0;
+    }
+}
+
+// Exact evaluation of up to MRZ_SMAX tag-equal entries of ONE candidate at position qx:
+// B->same_off[row][k] are the entries in probe order, B->pair_res[row][k] their per-lane
+// results ((len << 8) | rev, or -1 when an extension ran past the 64-byte reach).  Long
+// entries are extended by helper workgroups on other CUs (two or more of them) or by this
+// workgroup's striped path; then everything is folded in probe order (first longest wins,
+// src/rzip.c:446-450).  Accumulates into *xb/*xoff/*xrev/*xh/*xm.
+__device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_batch_lds *B, mrz_mailbox *mb,
+                                           int *mb_seq, int64_t qx, int nsx, int row, int lane, int64_t *stat,
+                                           int64_t *xb, int64_t *xoff, int64_t *xrev, int *xh, int *xm) {
+    const uint8_t *__restrict__ buf = C.buf;
+    bool farmed = false;
+#ifdef MRZ_SEQ_PROFILE
+    int64_t prof_t0 = (int64_t)__builtin_amdgcn_s_memtime();
+#endif
+#if MRZ_HELPER_WGS > 0
+    {
+        int nlong = 0;
+        for (int k = 0; k < nsx; k++)
+            if (mrz_uni(B->pair_res[row][k]) < 0) nlong++;
+        if (nlong >= 2 && nsx <= MRZ_HELPER_WGS && C.gmb) {
+            // hand every long entry to its own helper workgroup
+            mrz_gmailbox *g = C.gmb;
+            if (lane < nsx) {
+                // entries that are not long get an offset >= p0, which a helper answers with -1 at once
+                const bool is_long = B->pair_res[row][lane] < 0;
+                mrz_g_store(&g->op[lane], is_long ? (long long)B->same_off[row][lane] : (long long)qx);
+            }
+            if (lane == 0) {
+                const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
+                mrz_g_store(&g->p0, qx);
+                mrz_g_store(&g->maxf, C.end - qx);
+                mrz_g_store(&g->maxb_floor, floor_p);
+                mrz_g_storeu(&g->njobs, (unsigned long long)nsx);
+                mrz_g_storeu(&g->done, 0ull);
+            }
+            mrz_drain_stores();
+            *C.gseq += 1;
+            if (lane == 0) mrz_g_storeu(&g->seq, *C.gseq);
+            PROF_ADD(MRZ_ST_F_POST);
+            int spins = 0;
+            bool arrived = false;
+            while (!arrived && spins++ < MRZ_SPIN_LIMIT) {
+                arrived = mrz_uni((int)mrz_g_loadu(&g->done)) >= nsx;
+                if (!arrived) __builtin_amdgcn_s_sleep(2);
+            }
+            if (!arrived) {
+                if (lane == 0) C.st->error = 3;  // helpers never answered
+                return false;
+            }
+            farmed = true;
+            stat[MRZ_ST_FARMED] += 1;
+            PROF_ADD(MRZ_ST_F_WAIT);
+            for (int k = 0; k < nsx; k++) {
+                const int r = mrz_uni(B->pair_res[row][k]);
+                const int64_t op = mrz_uni64(B->same_off[row][k]);
+                int64_t ml, rv;
+                if (r < 0) {
+                    const int64_t fw = mrz_uni64(mrz_g_load(&g->fwd[k]));
+                    rv = mrz_uni64(mrz_g_load(&g->rev[k]));
+                    ml = fw + rv;
+                    if (fw < 0 || ml < MRZ_MIN_MATCH) ml = 0;
+                } else {
+                    ml = r >> 8;
+                    rv = r & 0xff;
+                }
+                if (ml) {
+                    if (ml > *xb) {
+                        *xb = ml;
+                        *xoff = op - rv;
+                        *xrev = rv;
+                    }
+                    *xh += 1;
+                } else
+                    *xm += 1;
+            }
+        }
+    }
+#endif
+    for (int k = 0; k < nsx && !farmed; k++) {
+        const int r = mrz_uni(B->pair_res[row][k]);
+        const int64_t op = mrz_uni64(B->same_off[row][k]);
+        int64_t ml, rv;
+        if (r < 0)
+            ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat);
+        else {
+            ml = r >> 8;
+            rv = r & 0xff;
+        }
+        if (ml) {
+            if (ml > *xb) {
+                *xb = ml;
+                *xoff = op - rv;
+                *xrev = rv;
+            }
+            *xh += 1;
+        } else
+            *xm += 1;
+    }
+    return true;
+}
+
+// One candidate, fully in order: the wave-cooperative path (any chain length,
+// any match length, cascades, chain-limit evictions, mask promotion).
+__device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_batch_lds *B, mrz_mailbox *mb, int *mb_seq,
+                                         int64_t *pend_h, int64_t *pend_t, int64_t *pend_o, int64_t t, int lane,
+                                         int64_t *stat) {
+    const uint8_t *__restrict__ buf = C.buf;
+    mrz_slot *tab = C.tab;
+    const int64_t p = L.p, end = C.end, slot_mask = C.slot_mask, max_chain = C.max_chain;
+    // ---- one pass over the chain: find_best_match (:426-462) and, when this
+    // position is inserted (:579), the probe walk of insert_hash ----------
+    const bool do_insert = (t & L.tag_mask) == L.tag_mask;
+    const int64_t better = (L.min_mask << 1) | 1;
+    const int my_rank = mrz_ones_rank(t);
+    int64_t mlen = 0, m_off = 0, m_rev = 0;
+    bool ins_found = !do_insert;
+    int64_t ins_slot = 0, occ_t = 0, occ_off = 0;
+    int ins_kind = 0;
+    if (do_insert) {
+        L.inserts++;
+        L.count++;
+    }
+    {
+        const int64_t h0 = t & slot_mask;
+        int64_t round = 0, victim_h = 0;
+        for (int64_t b = 0;; b += MRZ_WAVE) {
+            const int64_t s = (h0 + b + lane) & slot_mask;
+            const mrz_slot e = tab[s];
+            const bool empty = (e.off | e.t) == 0;
+            const mrz_u64 m_empty = __ballot(empty);
+            const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : MRZ_WAVE;
+            if (!ins_found)
+                ins_found = mrz_insert_step(e, empty, t, my_rank, h0 + b, slot_mask, better, max_chain, &round,
+                                            &victim_h, &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t,
+                                            &occ_off);
+            const mrz_u64 m_same = __ballot(!empty && e.t == t) & mrz_low_mask(first_empty);
+            mrz_u64 todo = m_same;
+            while (todo) {
+                // tag-equal entries of this step in probe order, MRZ_SMAX per pass: lane k takes the k-th
+                const int my_idx = __popcll(todo & mrz_low_mask(lane));
+                const bool is_mine = ((todo >> lane) & 1) && my_idx < MRZ_SMAX;
+                if (is_mine) B->same_off[0][my_idx] = e.off;
+                const int total = __popcll(todo);
+                const int npass = total < MRZ_SMAX ? total : MRZ_SMAX;
+                // drop the entries taken in this pass from `todo`
+                mrz_u64 rest = todo;
+                for (int k = 0; k < npass; k++) rest &= rest - 1;
+                MRZ_WAVE_SYNC();
+                if (lane < npass) {
+                    int64_t ml, rv;
+                    bool lng;
+                    mrz_lane_match_len(buf, p, B->same_off[0][lane], end, L.last_match, &ml, &rv, &lng);
+                    B->pair_res[0][lane] = lng ? -1 : (int)((ml << 8) | rv);
+                }
+                MRZ_WAVE_SYNC();
+                int xh = 0, xm = 0;
+                if (!mrz_resolve_entries(C, L, B, mb, mb_seq, p, npass, 0, lane, stat, &mlen, &m_off, &m_rev, &xh, &xm))
+                    return false;
+                L.tag_hits += xh;
+                L.tag_misses += xm;
+                todo = rest;
+            }
+            if (first_empty < MRZ_WAVE) break;
+        }
+    }
+
+    // ---- insert + cull (:579-584) -------------------------------------
+    if (do_insert) {
+        int np = 0;
+        int64_t it = t, io = p;
+        while (true) {
+            if (np >= MRZ_CASCADE_MAX) {  // cannot happen: every level has a strictly lower rank
+                if (lane == 0) C.st->error = 2;
+                return false;
+            }
+            if (lane == 0) {
+                pend_h[np] = ins_slot;
+                pend_t[np] = it;
+                pend_o[np] = io;
+            }
+            np++;
+            if (ins_kind != 2) break;
+            // re-insert the displaced occupant: its own probe walk
+            it = occ_t;
+            io = occ_off;
+            const int64_t h0 = it & slot_mask;
+            const int rank2 = mrz_ones_rank(it);
+            int64_t round = 0, victim_h = 0;
+            for (int64_t b = 0;; b += MRZ_WAVE) {
+                const int64_t s = (h0 + b + lane) & slot_mask;
+                const mrz_slot e = tab[s];
+                const bool empty = (e.off | e.t) == 0;
+                if (mrz_insert_step(e, empty, it, rank2, h0 + b, slot_mask, better, max_chain, &round, &victim_h,
+                                    &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t, &occ_off))
+                    break;
+            }
+        }
+        // write back innermost-first (the recursion's return order)
+        while (np-- > 0) {
+            const int64_t hs = mrz_uni64(pend_h[np]);
+            if (lane == 0) {
+                mrz_slot w;
+                w.off = pend_o[np];
+                w.t = pend_t[np];
+                tab[hs] = w;
+            }
+        }
+        if (L.count > C.limit) mrz_cull_one(C, L, lane);
+    }
+    return mrz_select_emit(C, L, mlen, m_off, m_rev, lane);
+}
+
+// ---- the batch engine -------------------------------------------------------------
+// Up to 64 consecutive candidates are processed at once, ONE LANE PER CANDIDATE,
+// against the table as it stands at the start of the batch:
+//   1. every lane walks its own probe chain (4 slots = 64 B per step) and records
+//      first-empty, the tag-equal entries, and where insert_hash's walk stops
+//      (empty / due-for-culling overwrite / lower-ranked occupant to displace / the
+//      max_chain_len-th tag-equal entry => victim eviction);
+//   1b. lanes that displace an occupant walk that occupant's chain too;
+//   2. every lane extends its tag-equal candidates itself, 64 B each way;
+//   3. wave scans turn the per-lane facts into the sequential quantities:
+//      victim_round per evicting lane (prefix count), hash_count before each lane
+//      (saturating prefix sum), which lanes cull and which sweep entry each culls
+//      (rank into the ballot of failing entries ahead of tag_clean_ptr);
+//   4. a lane may only be committed if no EARLIER lane's write (insert, displaced
+//      re-insert, cull) falls inside the slots it read: an LDS filter keyed by
+//      64-slot block flags suspects, suspects are checked exactly.  The batch is
+//      cut at the first lane that conflicts or needs the cooperative path
+//      (long match, long chain, deep cascade, sweep wrap, mask transition), the
+//      lazy-match fold (:586-599) may cut it earlier at an emission;
+//   5. all surviving lanes write their slots in one go.
+// The committed prefix is exactly what the reference's loop would have done.
 // Returns the number of candidates consumed from this window (>= 1), or 0 when the
 // first candidate has to go through mrz_seq_candidate.  `w` is this lane's bitmap
 // word of the 4096-position window starting at `wb`, already masked to (L.p, lim].
@@ -1180,101 +1367,9 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         const int64_t qx = mrz_bcast64(q, x);
         int64_t xb = 0, xoff = 0, xrev = 0;
         int xh = 0, xm = 0;
-        bool farmed = false;
-#if MRZ_HELPER_WGS > 0
-        {
-            // hand every long entry of this lane to its own helper workgroup
-            int nlong = 0;
-            for (int k = 0; k < nsx; k++)
-                if (mrz_uni(B->pair_res[x][k]) < 0) nlong++;
-            if (nlong >= 2 && nsx <= MRZ_HELPER_WGS && C.gmb) {
-                mrz_gmailbox *g = C.gmb;
-                if (lane < nsx) {
-                    // entries that are not long get an offset >= p0, which a helper answers with -1 at once
-                    const bool is_long = B->pair_res[x][lane] < 0;
-                    mrz_g_store(&g->op[lane], is_long ? (long long)B->same_off[x][lane] : (long long)qx);
-                }
-                if (lane == 0) {
-                    const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
-                    mrz_g_store(&g->p0, qx);
-                    mrz_g_store(&g->maxf, C.end - qx);
-                    mrz_g_store(&g->maxb_floor, floor_p);
-                    mrz_g_storeu(&g->njobs, (unsigned long long)nsx);
-                    mrz_g_storeu(&g->done, 0ull);
-                }
-                mrz_drain_stores();
-                *C.gseq += 1;
-                if (lane == 0) mrz_g_storeu(&g->seq, *C.gseq);
-                PROF_ADD(MRZ_ST_F_POST);
-                int spins = 0;
-                bool arrived = false;
-                while (!arrived && spins++ < MRZ_SPIN_LIMIT) {
-                    arrived = mrz_uni((int)mrz_g_loadu(&g->done)) >= nsx;
-                    if (!arrived) __builtin_amdgcn_s_sleep(2);
-                }
-                if (!arrived) {
-                    if (lane == 0) C.st->error = 3;  // helpers never answered
-                    *ok = false;
-                    return 0;
-                }
-                farmed = true;
-                stat[MRZ_ST_FARMED] += 1;
-                PROF_ADD(MRZ_ST_F_WAIT);
-#ifdef MRZ_SEQ_PROFILE
-                {
-                    long long hmax = 0;
-                    for (int k = 0; k < nsx; k++) {
-                        const long long hv = mrz_uni64(mrz_g_load(&g->dbg[k]));
-                        if (mrz_uni(B->pair_res[x][k]) < 0 && hv > hmax) hmax = hv;
-                    }
-                    stat[MRZ_ST_F_HELPER] += hmax;
-                }
-#endif
-                for (int k = 0; k < nsx; k++) {
-                    const int r = mrz_uni(B->pair_res[x][k]);
-                    const int64_t op = mrz_uni64(B->same_off[x][k]);
-                    int64_t ml, rv;
-                    if (r < 0) {
-                        const int64_t fw = mrz_uni64(mrz_g_load(&g->fwd[k]));
-                        rv = mrz_uni64(mrz_g_load(&g->rev[k]));
-                        ml = fw + rv;
-                        if (fw < 0 || ml < MRZ_MIN_MATCH) ml = 0;
-                    } else {
-                        ml = r >> 8;
-                        rv = r & 0xff;
-                    }
-                    if (ml) {  // first longest wins, :446-450
-                        if (ml > xb) {
-                            xb = ml;
-                            xoff = op - rv;
-                            xrev = rv;
-                        }
-                        xh++;
-                    } else
-                        xm++;
-                }
-            }
-        }
-#endif
-        for (int k = 0; k < nsx && !farmed; k++) {
-            const int r = mrz_uni(B->pair_res[x][k]);
-            const int64_t op = mrz_uni64(B->same_off[x][k]);
-            int64_t ml, rv;
-            if (r < 0)
-                ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat);
-            else {
-                ml = r >> 8;
-                rv = r & 0xff;
-            }
-            if (ml) {  // first longest wins, :446-450
-                if (ml > xb) {
-                    xb = ml;
-                    xoff = op - rv;
-                    xrev = rv;
-                }
-                xh++;
-            } else
-                xm++;
+        if (!mrz_resolve_entries(C, L, B, mb, mb_seq, qx, nsx, x, lane, stat, &xb, &xoff, &xrev, &xh, &xm)) {
+            *ok = false;
+            return 0;
         }
         PROF_ADD(MRZ_ST_T_LONG);
         if (lane == x) {
@@ -1405,9 +1500,27 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         mb->seq = 0;
         mb->done = 0;
         mb->quit = 0;
+        mb->scout_seq = 0;
+        mb->scout_pos = st->p;
+        mb->scout_clean = st->clean_ptr;
     }
     for (int i = threadIdx.x; i < MRZ_FILTER_SIZE; i += MRZ_SEQ_THREADS) batch.filter[i] = 0;
     __syncthreads();
+    if (MRZ_HAVE_SCOUT && wave == MRZ_SEQ_WAVES - 1) {
+        mrz_scout_args S;
+        S.buf = a.buf;
+        S.tab = a.tab;
+        S.tags = a.tags;
+        S.bitmap = a.bitmap;
+        S.seg_start = a.seg_start;
+        const int64_t s_end = a.seg_start + a.seg_len;
+        S.lim = (st->end < s_end - 1) ? st->end : s_end - 1;
+        S.nwords = (a.seg_len + 63) / 64;
+        S.slot_mask = st->slot_mask;
+        S.nslots = st->slot_mask + 1;
+        mrz_scout_loop(S, mb, lane);
+        return;
+    }
     if (wave != 0) {
         mrz_helper_loop(a.buf, mb, wave, lane);
         return;
@@ -1454,12 +1567,25 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     unsigned epoch = 1;
     bool ok = true;
     int width = 64;            // batch width, adapted to how many lanes recent batches could commit
+    int low_yield = 0;         // consecutive batches that committed <= 2 candidates
+    int seq_credit = 0;        // candidates to run through the cooperative path before batching again
     bool prefer_seq = false;   // right after an emission the next candidate is usually a long match
     int64_t stat[MRZ_ST_N];
     for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
 
+    int sc_seq = 0;
+    int64_t sc_last = -1;
     while (ok) {
         PROF_T0();
+        if (MRZ_HAVE_SCOUT && L.p != sc_last) {
+            sc_last = L.p;
+            sc_seq++;
+            if (lane == 0) {
+                mb->scout_pos = L.p;
+                mb->scout_clean = L.clean_ptr;
+                mrz_mb_store(&mb->scout_seq, sc_seq);
+            }
+        }
         // ---- the 4096-position bitmap window that holds position p + 1 ------------
         int64_t pos = L.p + 1;
         if (pos < seg_start) pos = seg_start;
@@ -1492,7 +1618,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         int used = 0;
         const int64_t ev_before = L.n_events;
 #ifndef MRZ_NO_BATCH
-        if (!prefer_seq) {
+        if (seq_credit > 0)
+            seq_credit--;  // a stretch where every candidate has long matches: one at a time is cheaper
+        else if (!prefer_seq) {
             used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, width, lane, &ok, stat, mb, &mb_seq);
             epoch++;
             // adapt the width: shrink towards what could be committed, grow back when all of it was
@@ -1502,6 +1630,13 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 const int want = 2 * used + 4;
                 width = want < 8 ? 8 : (want > 64 ? 64 : want);
             }
+            if (used <= 2) {
+                if (++low_yield >= MRZ_LOW_YIELD_RUNS) {
+                    seq_credit = MRZ_SEQ_CREDIT;
+                    low_yield = 0;
+                }
+            } else
+                low_yield = 0;
         }
 #endif
         prefer_seq = false;
@@ -1516,7 +1651,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             L.p = wb + (int64_t)fl * 64 + (__ffsll((long long)wl) - 1);
             const int64_t t = mrz_uni64(a.tags[L.p - seg_start]);
             if ((t & L.min_mask) == L.min_mask)  // src/rzip.c:573 with the mask reached by now
-                ok = mrz_seq_candidate(C, L, mb, &mb_seq, pend_h, pend_t, pend_o, t, lane);
+                ok = mrz_seq_candidate(C, L, &batch, mb, &mb_seq, pend_h, pend_t, pend_o, t, lane, stat);
             PROF_ADD(MRZ_ST_T_SEQ);
         }
         (void)ev_before;
