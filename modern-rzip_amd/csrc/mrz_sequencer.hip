@@ -22,9 +22,8 @@
 //     * cascades of displaced occupants are collected and written back
 //       innermost-first exactly like the reference's recursion;
 //     * clean_one_from_hash (:305-328): 64 slots per sweep step.
-//     * single_match_len (:372-397), short path: up to 8 tag-equal entries at
-//       once, 8 lanes x 16 B each, forwards and backwards in ONE load round trip
-//       (most candidates differ within 128 bytes);
+//     * single_match_len (:372-397): every tag-equal entry of a step is extended by
+//       its own lane, 64 B each way, in one load round trip (most differ there);
 //   waves 1..W-1 ("helpers") wait on an LDS mailbox.  A candidate that runs
 //   past 128 bytes takes the long path: its forward extension is striped over
 //   all W waves (W x 4 KiB per round, every wave 64 lanes x 16 B x 4 pieces,
@@ -261,75 +260,6 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
     return len < MRZ_MIN_MATCH ? 0 : len;
 }
 
-#define MRZ_SHORT_BYTES 128  // reach of the 8-lane short path, each direction
-
-// Short path: up to 8 tag-equal candidates at once, 8 lanes (128 B) each,
-// forwards and backwards in a single load round trip.  Per group (lane>>3):
-// *len / *rev as single_match_len would return them, or *is_long when either
-// direction ran through all 128 bytes (the caller then uses the striped path).
-__device__ static void mrz_short_match_len(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, bool valid,
-                                           int64_t end, int64_t last_match, int lane, int64_t *len, int64_t *rev,
-                                           bool *is_long) {
-    const int i = lane & 7;
-    const int g8 = lane & ~7;
-    const int64_t off = (int64_t)i * 16;
-    valid = valid && op < p0;
-    const int64_t maxf = end - p0;
-    int f_len = 0;
-    bool f_full = false;
-    uint4 fa, fb, ba, bb;
-    const bool f_act = valid && off < maxf;
-    if (f_act) {
-        fa = mrz_ld16(buf + p0 + off);
-        fb = mrz_ld16(buf + op + off);
-    }
-    const int64_t floor_p = last_match > 0 ? last_match : 0;
-    int64_t maxb = p0 - floor_p;
-    if (op < maxb) maxb = op;
-    const bool b_act = valid && off < maxb;
-    const bool b_wide = b_act && (op - off - 16 >= 0);
-    if (b_wide) {
-        ba = mrz_ld16(buf + p0 - off - 16);
-        bb = mrz_ld16(buf + op - off - 16);
-    }
-    if (f_act) {
-        const int64_t rem = maxf - off;
-        const int lim = rem < 16 ? (int)rem : 16;
-        const int d = mrz_first_diff16(fa, fb);
-        f_len = d < lim ? d : lim;
-        f_full = f_len == 16;
-    }
-    int b_len = 0;
-    bool b_full = false;
-    if (b_act) {
-        const int64_t rem = maxb - off;
-        const int lim = rem < 16 ? (int)rem : 16;
-        int cnt;
-        if (b_wide)
-            cnt = mrz_top_equal16(ba, bb);
-        else {
-            cnt = 0;
-            while (cnt < lim && buf[p0 - off - 1 - cnt] == buf[op - off - 1 - cnt]) cnt++;
-        }
-        b_len = cnt < lim ? cnt : lim;
-        b_full = b_len == 16;
-    }
-    const mrz_u64 f_stop = __ballot(!f_full);
-    const mrz_u64 b_stop = __ballot(!b_full);
-    const unsigned fbits = (unsigned)(f_stop >> g8) & 0xffu;
-    const unsigned bbits = (unsigned)(b_stop >> g8) & 0xffu;
-    const int ffi = fbits ? __ffs((int)fbits) - 1 : 0;
-    const int bfi = bbits ? __ffs((int)bbits) - 1 : 0;
-    const int f_at = __shfl(f_len, g8 + ffi, MRZ_WAVE);
-    const int b_at = __shfl(b_len, g8 + bfi, MRZ_WAVE);
-    const int64_t fwd = ffi * 16 + f_at;
-    const int64_t rv = bfi * 16 + b_at;
-    *is_long = valid && (fbits == 0 || bbits == 0);
-    *rev = valid ? rv : 0;
-    const int64_t l = fwd + rv;
-    *len = (valid && l >= MRZ_MIN_MATCH) ? l : 0;
-}
-
 // One 64-slot step of insert_hash's probe walk (src/rzip.c:264-297) over the
 // slots already loaded into `e`.  round / victim_h carry across steps.
 // Returns true when the walk stops in this step; then *stop_slot is the slot to
@@ -487,7 +417,7 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 // are polled with relaxed agent-scope loads and s_sleep.  The compared bytes themselves are
 // read-only input.  All spins are bounded.
 #ifndef MRZ_HELPER_WGS
-#define MRZ_HELPER_WGS 16
+#define MRZ_HELPER_WGS 16  // one workgroup per entry; spreading an entry over 4 workgroups (64 in all) measured slower
 #endif
 #define MRZ_SPIN_LIMIT (1 << 22)          // leader: ~1 s of polling for an answer that takes microseconds
 #define MRZ_HELPER_SPIN_LIMIT (1ll << 34)  // helpers: idle for as long as a launch may run
@@ -841,13 +771,24 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
             farmed = true;
             stat[MRZ_ST_FARMED] += 1;
             PROF_ADD(MRZ_ST_F_WAIT);
+            // every lane fetches one entry's answer (one round trip for all of them)
+            int64_t my_fw = 0, my_rv = 0, my_op = 0;
+            int my_r = 0;
+            if (lane < nsx) {
+                my_r = B->pair_res[row][lane];
+                my_op = B->same_off[row][lane];
+                if (my_r < 0) {
+                    my_fw = mrz_g_load(&g->fwd[lane]);
+                    my_rv = mrz_g_load(&g->rev[lane]);
+                }
+            }
             for (int k = 0; k < nsx; k++) {
-                const int r = mrz_uni(B->pair_res[row][k]);
-                const int64_t op = mrz_uni64(B->same_off[row][k]);
+                const int r = mrz_lane_read(my_r, k);
+                const int64_t op = mrz_bcast64(my_op, k);
                 int64_t ml, rv;
                 if (r < 0) {
-                    const int64_t fw = mrz_uni64(mrz_g_load(&g->fwd[k]));
-                    rv = mrz_uni64(mrz_g_load(&g->rev[k]));
+                    const int64_t fw = mrz_bcast64(my_fw, k);
+                    rv = mrz_bcast64(my_rv, k);
                     ml = fw + rv;
                     if (fw < 0 || ml < MRZ_MIN_MATCH) ml = 0;
                 } else {
