@@ -164,6 +164,16 @@ int mrz_blake2b_final(mrz_blake2b *st, void *out_host, size_t outlen); /* frees 
 int mrz_blake2b_batch(mrz_ctx *ctx, const void *const *msgs, const int64_t *lens, int count, int where, size_t outlen,
                       uint8_t *out_host);
 
+/* ---- rs-mrzip encoder (the "next" row after the rzip stage) ------------------ */
+
+/* Replaces encode() of rs-mrzip (rs-mrzip/rs-mrzip.c:119-158): for every 223-byte row
+ * the CCSDS RS(255,223) dual-basis parity (rse32, rs-mrzip/reed-solomon.c:115-141), bursts
+ * of 8176 rows interleaved column-major (scatter, :311-321), then BLAKE2b-512 of the padded
+ * rows and the 4-byte {k_i, k_j} trailer.  `out` receives exactly what `rs-mrzip` writes to
+ * stdout for `n` bytes of stdin: mrz_rs_encoded_size(n) bytes. */
+int64_t mrz_rs_encoded_size(int64_t n);
+int mrz_rs_encode(mrz_ctx *ctx, const void *in, int64_t n, int where, void *out, int out_where, int64_t out_cap);
+
 #ifdef __cplusplus
 }
 #endif

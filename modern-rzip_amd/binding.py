@@ -94,6 +94,10 @@ def load_library(path=None):
         lib.mrz_blake2b_update.argtypes = [vp, vp, ctypes.c_size_t, ci]
         lib.mrz_blake2b_final.argtypes = [vp, vp, ctypes.c_size_t]
         lib.mrz_blake2b_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64), ci, ci, ctypes.c_size_t, vp]
+    if hasattr(lib, "mrz_rs_encode"):
+        lib.mrz_rs_encoded_size.argtypes = [i64]
+        lib.mrz_rs_encoded_size.restype = i64
+        lib.mrz_rs_encode.argtypes = [vp, vp, i64, ci, vp, ci, i64]
     if hasattr(lib, "mrz_rzip_buffer"):
         lib.mrz_rzip_buffer.argtypes = [ctypes.POINTER(Control), vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                         ctypes.POINTER(Stats), vp]
@@ -227,6 +231,14 @@ class RzipContext:
         out = (ctypes.c_int * len(prep))()
         _check(self.lib, self.lib.mrz_lz4_sizes(self.ctx, ptrs, lens, len(prep), prep[0][2], out), self.ctx)
         return list(out)
+
+    # ---- rs-mrzip encoder (rs-mrzip/rs-mrzip.c:119-158) ----
+    def rs_encode(self, data):
+        ptr, n, where, keep = _as_ptr(data)
+        total = self.lib.mrz_rs_encoded_size(n)
+        out = ctypes.create_string_buffer(total)
+        _check(self.lib, self.lib.mrz_rs_encode(self.ctx, ptr, n, where, out, MEM_HOST, total), self.ctx)
+        return out.raw
 
     # ---- BLAKE2b (common/blake2b.h:47-49) ----
     def blake2b(self, data, outlen=64, pieces=None):

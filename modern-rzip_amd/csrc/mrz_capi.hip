@@ -88,6 +88,8 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_crc_parts);
     hipFree(ctx->d_crc_out);
     if (ctx->d_gmailbox) hipFree(ctx->d_gmailbox);
+    if (ctx->d_rs_tables) hipFree(ctx->d_rs_tables);
+    if (ctx->d_rs_out) hipFree(ctx->d_rs_out);
     if (ctx->lz4_scratch) hipFree(ctx->lz4_scratch);
     if (ctx->b2_scratch) hipFree(ctx->b2_scratch);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);

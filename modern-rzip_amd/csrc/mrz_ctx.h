@@ -44,6 +44,9 @@ struct mrz_ctx {
     int64_t crc_parts_cap;
     uint32_t *d_crc_out;
     void *d_gmailbox;  // mailbox of the sequencer's helper workgroups
+    void *d_rs_tables;  // Reed-Solomon tables (mrz_rs.hip)
+    uint8_t *d_rs_out;
+    int64_t rs_out_cap;
     int have_chunk;
 
     // LZ4 / BLAKE2b scratch (owned by their translation units, freed in mrz_close)

@@ -1,0 +1,336 @@
+// mrz_rs.hip -- rs-mrzip's encoder on the GPU: CCSDS RS(255,223) parity in Berlekamp's dual
+// basis for every 223-byte row, and the burst interleave, fused.
+//
+// Restates rse32 (rs-mrzip/reed-solomon.c:115-141), scatter (:311-321) and the burst loop of
+// encode() (rs-mrzip/rs-mrzip.c:119-158).  The reference encodes one row after another on one
+// core; the 8176 rows of a burst (and all bursts) are independent, so:
+//   * a 128-thread workgroup takes 112 consecutive rows (8176 = 73 x 112): their 24,976 input
+//     bytes are loaded coalesced (16 B per lane) into an LDS image with 255-byte rows;
+//   * thread t runs the 32-byte LFSR of row t: per data byte one dual->conventional look-up, one
+//     32-byte row of the precomputed "feedback x generator" table (256 x 32 B in LDS, two
+//     ds_read_b128) XORed into the shifted register held in 8 dwords -- the log/antilog
+//     arithmetic of the reference (:122-134) is folded into that table;
+//   * the 32 parity bytes go back through the conventional->dual table into columns 223..254 of
+//     the LDS image, and the image is written out transposed (column c of row r at
+//     c * 8176 + r, :311-321) as dwords: 4 rows per lane, 112 contiguous bytes per column.
+// The data columns are written unchanged (taltab o tal1tab = identity, :118,138).
+// Tables are generated on the host from the field polynomial, the generator roots and the 8
+// dual-basis images; nothing is copied from the reference.
+//
+// Bound: HBM -- 223 B read + 255 B written per row (478 B per row).
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "mrz_ctx.h"
+#include "mrz_device.h"
+
+#define MRZ_RS_ROWS 8176  // BLK_LEN, rs-mrzip/reed-solomon.h:31
+#define MRZ_RS_K 223
+#define MRZ_RS_N 255
+#define MRZ_RS_TILE 112   // rows per workgroup; 8176 = 73 * 112
+#define MRZ_RS_THREADS 128
+
+struct mrz_rs_tables {
+    uint8_t fbgen[256][32];  // fbgen[f][j] = f * g_j in GF(256), conventional basis
+    uint8_t tal[256];        // conventional -> dual basis
+    uint8_t tal1[256];       // dual -> conventional
+};
+
+static void mrz_rs_build_tables(mrz_rs_tables *T) {
+    uint8_t ex[256], lg[256];
+    unsigned v = 1;
+    for (int i = 0; i < 255; i++) {  // GF(2^8), p(x) = x^8 + x^7 + x^2 + x + 1, alpha = 2
+        ex[i] = (uint8_t)v;
+        lg[v] = (uint8_t)i;
+        v <<= 1;
+        if (v & 0x100) v ^= 0x187;
+    }
+    auto mul = [&](uint8_t a, uint8_t b) -> uint8_t { return (!a || !b) ? 0 : ex[(lg[a] + lg[b]) % 255]; };
+    uint8_t g[33] = { 1 };  // g(x) = prod_{j=112..143} (x - alpha^(11 j))
+    for (int j = 112, deg = 0; j <= 143; j++, deg++) {
+        const uint8_t root = ex[(11 * j) % 255];
+        g[deg + 1] = 0;
+        for (int k = deg + 1; k > 0; k--) g[k] = g[k - 1] ^ mul(g[k], root);
+        g[0] = mul(g[0], root);
+    }
+    for (int f = 0; f < 256; f++)
+        for (int j = 0; j < 32; j++) T->fbgen[f][j] = mul((uint8_t)f, g[j]);
+    static const uint8_t basis[8] = { 0x8d, 0xef, 0xec, 0x86, 0xfa, 0x99, 0xaf, 0x7b };
+    for (int i = 0; i < 256; i++) {
+        uint8_t t = 0;
+        for (int k = 0; k < 8; k++)
+            if (i & (1 << k)) t ^= basis[7 - k];
+        T->tal[i] = t;
+    }
+    for (int i = 0; i < 256; i++) T->tal1[T->tal[i]] = (uint8_t)i;
+}
+
+// grid.x = bursts * 73; each workgroup: 112 rows of one burst
+__global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uint8_t *__restrict__ in, int64_t n,
+                                                                       const mrz_rs_tables *__restrict__ T,
+                                                                       uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_fb[256][32];
+    __shared__ uint8_t s_tal[256], s_tal1[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[MRZ_RS_TILE * MRZ_RS_N + 16];
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 256 * 32 / 16; i += MRZ_RS_THREADS)
+        reinterpret_cast<uint4 *>(&s_fb[0][0])[i] = reinterpret_cast<const uint4 *>(&T->fbgen[0][0])[i];
+    for (int i = tid; i < 256; i += MRZ_RS_THREADS) {
+        s_tal[i] = T->tal[i];
+        s_tal1[i] = T->tal1[i];
+    }
+    const int64_t burst = blockIdx.x / (MRZ_RS_ROWS / MRZ_RS_TILE);
+    const int tile = blockIdx.x % (MRZ_RS_ROWS / MRZ_RS_TILE);
+    const int64_t row0 = burst * MRZ_RS_ROWS + (int64_t)tile * MRZ_RS_TILE;  // global row index
+    const int64_t in0 = row0 * MRZ_RS_K;
+    // stage 112 x 223 input bytes (zero beyond n, rs-mrzip.c:132-133) into 255-byte LDS rows
+    const int tile_bytes = MRZ_RS_TILE * MRZ_RS_K;
+    for (int x = tid * 16; x < tile_bytes; x += MRZ_RS_THREADS * 16) {
+        uint8_t tmp[16];
+        const int64_t gpos = in0 + x;
+        if (gpos + 16 <= n) {
+            const uint4 v = mrz_ld16(in + gpos);
+            __builtin_memcpy(tmp, &v, 16);
+        } else {
+            for (int k = 0; k < 16; k++) tmp[k] = (gpos + k < n) ? in[gpos + k] : (uint8_t)0;
+        }
+        int r = x / MRZ_RS_K, c = x % MRZ_RS_K;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (x + k < tile_bytes) s_img[r * MRZ_RS_N + c] = tmp[k];
+            if (++c == MRZ_RS_K) {
+                c = 0;
+                r++;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < MRZ_RS_TILE) {
+        // rse32: bb[j] = bb[j-1] ^ g_j * feedback, bb[0] = g_0 * feedback  (:120-135)
+        uint32_t b[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        const uint8_t *row = &s_img[tid * MRZ_RS_N];
+        for (int i = MRZ_RS_K - 1; i >= 0; i--) {
+            const uint32_t fb = (uint32_t)s_tal1[row[i]] ^ (b[7] >> 24);
+#pragma unroll
+            for (int k = 7; k > 0; k--) b[k] = (b[k] << 8) | (b[k - 1] >> 24);
+            b[0] <<= 8;
+            const uint4 g0 = *reinterpret_cast<const uint4 *>(&s_fb[fb][0]);
+            const uint4 g1 = *reinterpret_cast<const uint4 *>(&s_fb[fb][16]);
+            b[0] ^= g0.x;
+            b[1] ^= g0.y;
+            b[2] ^= g0.z;
+            b[3] ^= g0.w;
+            b[4] ^= g1.x;
+            b[5] ^= g1.y;
+            b[6] ^= g1.z;
+            b[7] ^= g1.w;
+        }
+        uint8_t *par = &s_img[tid * MRZ_RS_N + MRZ_RS_K];
+#pragma unroll
+        for (int j = 0; j < 32; j++) par[j] = s_tal[(b[j >> 2] >> (8 * (j & 3))) & 0xff];  // :138
+    }
+    __syncthreads();
+    // scatter (:311-321): dst[c * 8176 + r] = row r, column c; 4 rows per dword store
+    uint8_t *dst = out + burst * (int64_t)MRZ_RS_N * MRZ_RS_ROWS + (int64_t)tile * MRZ_RS_TILE;
+    const int quads = MRZ_RS_TILE / 4;  // 28
+    for (int idx = tid; idx < MRZ_RS_N * quads; idx += MRZ_RS_THREADS) {
+        const int c = idx / quads, u = idx % quads;
+        const uint8_t *p = &s_img[(4 * u) * MRZ_RS_N + c];
+        const uint32_t w = (uint32_t)p[0] | (uint32_t)p[MRZ_RS_N] << 8 | (uint32_t)p[2 * MRZ_RS_N] << 16 |
+                           (uint32_t)p[3 * MRZ_RS_N] << 24;
+        *reinterpret_cast<uint32_t *>(dst + (int64_t)c * MRZ_RS_ROWS + 4 * u) = w;
+    }
+}
+
+// ---- BLAKE2b-512 on the host (the trailer hash of rs-mrzip.c:138,148 is one serial chain over
+// the whole padded stream; it runs on a host thread while the GPU encodes) ---------------------
+namespace {
+struct HostB2 {
+    uint64_t h[8], t0 = 0, t1 = 0;
+    uint8_t buf[128];
+    size_t buflen = 0;
+    static uint64_t ror(uint64_t x, int c) { return (x >> c) | (x << (64 - c)); }
+    HostB2() {
+        static const uint64_t iv[8] = { 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                                        0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                                        0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL };
+        for (int i = 0; i < 8; i++) h[i] = iv[i];
+        h[0] ^= 0x01010000ULL ^ 64;
+    }
+    void compress(const uint8_t *blk, bool last) {
+        static const uint64_t iv[8] = { 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                                        0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                                        0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL };
+        static const uint8_t sg[10][16] = {
+            { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 }, { 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3 },
+            { 11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4 }, { 7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8 },
+            { 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13 }, { 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9 },
+            { 12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11 }, { 13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10 },
+            { 6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5 }, { 10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0 }
+        };
+        uint64_t m[16], v[16];
+        memcpy(m, blk, 128);
+        for (int i = 0; i < 8; i++) {
+            v[i] = h[i];
+            v[i + 8] = iv[i];
+        }
+        v[12] ^= t0;
+        v[13] ^= t1;
+        if (last) v[14] = ~v[14];
+        static const int q[8][4] = { { 0, 4, 8, 12 }, { 1, 5, 9, 13 }, { 2, 6, 10, 14 }, { 3, 7, 11, 15 },
+                                     { 0, 5, 10, 15 }, { 1, 6, 11, 12 }, { 2, 7, 8, 13 }, { 3, 4, 9, 14 } };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *s = sg[r % 10];
+            for (int g = 0; g < 8; g++) {
+                uint64_t &a = v[q[g][0]], &b = v[q[g][1]], &c = v[q[g][2]], &d = v[q[g][3]];
+                a += b + m[s[2 * g]];
+                d = ror(d ^ a, 32);
+                c += d;
+                b = ror(b ^ c, 24);
+                a += b + m[s[2 * g + 1]];
+                d = ror(d ^ a, 16);
+                c += d;
+                b = ror(b ^ c, 63);
+            }
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void count(uint64_t inc) {
+        t0 += inc;
+        if (t0 < inc) t1++;
+    }
+    void update(const uint8_t *p, size_t n) {
+        while (n) {
+            if (buflen == 128) {
+                count(128);
+                compress(buf, false);
+                buflen = 0;
+            }
+            size_t take = 128 - buflen;
+            if (take > n) take = n;
+            memcpy(buf + buflen, p, take);
+            buflen += take;
+            p += take;
+            n -= take;
+        }
+    }
+    void zeros(uint64_t n) {
+        static const uint8_t z[4096] = { 0 };
+        while (n) {
+            const size_t take = n > sizeof(z) ? sizeof(z) : (size_t)n;
+            update(z, take);
+            n -= take;
+        }
+    }
+    void final(uint8_t out[64]) {
+        count(buflen);
+        memset(buf + buflen, 0, 128 - buflen);
+        compress(buf, true);
+        memcpy(out, h, 64);
+    }
+};
+}  // namespace
+
+extern "C" int64_t mrz_rs_encoded_size(int64_t n) {
+    if (n < 0) return MRZ_E_ARG;
+    const int64_t burst_in = (int64_t)MRZ_RS_K * MRZ_RS_ROWS;
+    return (n / burst_in + 1) * (int64_t)MRZ_RS_N * MRZ_RS_ROWS + 64 + 4;  // feof() needs a short read (rs-mrzip.c:125)
+}
+
+extern "C" int mrz_rs_encode(mrz_ctx *ctx, const void *in, int64_t n, int where, void *out, int out_where,
+                             int64_t out_cap) {
+    if (!ctx || n < 0 || (n > 0 && !in) || !out) return MRZ_E_ARG;
+    const int64_t total = mrz_rs_encoded_size(n);
+    if (out_cap < total) return MRZ_E_ARG;
+    if (out_where != MRZ_MEM_HOST && out_where != MRZ_MEM_DEVICE) return MRZ_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t burst_in = (int64_t)MRZ_RS_K * MRZ_RS_ROWS, burst_out = (int64_t)MRZ_RS_N * MRZ_RS_ROWS;
+    const int64_t nbursts = n / burst_in + 1;
+
+    // the serial trailer hash runs on a host thread (host input) or after a device->host copy
+    std::vector<uint8_t> host_copy;
+    const uint8_t *h_in = (const uint8_t *)in;
+    const uint8_t *d_in = nullptr;
+    int rc = mrz_stage_input(ctx, in, n, where, &d_in);
+    if (rc) return rc;
+    if (where == MRZ_MEM_DEVICE) {
+        host_copy.resize((size_t)n);
+        if (n) HIPCHK(ctx, hipMemcpy(host_copy.data(), in, (size_t)n, hipMemcpyDeviceToHost));
+        h_in = host_copy.data();
+    }
+    uint8_t digest[64];
+    std::thread hasher([&]() {
+        HostB2 b;
+        b.update(h_in, (size_t)n);
+        b.zeros((uint64_t)(nbursts * burst_in - n));  // the padded rows are hashed too (rs-mrzip.c:132-138)
+        b.final(digest);
+    });
+
+    if (!ctx->d_rs_tables) {
+        mrz_rs_tables *T = (mrz_rs_tables *)malloc(sizeof(mrz_rs_tables));
+        void *p = nullptr;
+        hipError_t e = T ? hipMalloc(&p, sizeof(mrz_rs_tables)) : hipErrorOutOfMemory;
+        if (e == hipSuccess) {
+            mrz_rs_build_tables(T);
+            e = hipMemcpy(p, T, sizeof(mrz_rs_tables), hipMemcpyHostToDevice);
+        }
+        free(T);
+        if (e != hipSuccess) {
+            hasher.join();
+            ctx->last_err = e;
+            return MRZ_E_NOMEM;
+        }
+        ctx->d_rs_tables = p;
+    }
+    uint8_t *d_out = (uint8_t *)out;
+    if (out_where == MRZ_MEM_HOST) {
+        rc = mrz_grow(ctx, &ctx->d_rs_out, &ctx->rs_out_cap, nbursts * burst_out);
+        if (rc) {
+            hasher.join();
+            return rc;
+        }
+        d_out = ctx->d_rs_out;
+    }
+    hipError_t e = hipSuccess;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (ctx->profiling) {
+        hipEventCreate(&ea);
+        hipEventCreate(&eb);
+        hipEventRecord(ea, ctx->stream);
+    }
+    hipLaunchKernelGGL(mrz_rs_encode_kernel, dim3((unsigned)(nbursts * (MRZ_RS_ROWS / MRZ_RS_TILE))), dim3(MRZ_RS_THREADS),
+                       0, ctx->stream, d_in, n, (const mrz_rs_tables *)ctx->d_rs_tables, d_out);
+    e = hipGetLastError();
+    if (ctx->profiling) hipEventRecord(eb, ctx->stream);
+    if (e == hipSuccess && out_where == MRZ_MEM_HOST)
+        e = hipMemcpyAsync(out, d_out, (size_t)(nbursts * burst_out), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (ctx->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ea, eb) == hipSuccess) ctx->timings.encode_ms = ms;  // reported via mrz_get_timings
+        hipEventDestroy(ea);
+        hipEventDestroy(eb);
+    }
+    hasher.join();
+    if (e != hipSuccess) {
+        ctx->last_err = e;
+        return MRZ_E_HIP;
+    }
+    // trailer: BLAKE2b-512 + k_i, k_j (first short row and its length, rs-mrzip.c:128-136,148-157)
+    const int64_t rem = n - (nbursts - 1) * burst_in;
+    const unsigned k_i = (unsigned)(rem / MRZ_RS_K), k_j = (unsigned)(rem % MRZ_RS_K);
+    uint8_t tail[68];
+    memcpy(tail, digest, 64);
+    tail[64] = (uint8_t)(k_i & 0xff);
+    tail[65] = (uint8_t)(k_i >> 8);
+    tail[66] = (uint8_t)(k_j & 0xff);
+    tail[67] = (uint8_t)(k_j >> 8);
+    if (out_where == MRZ_MEM_HOST)
+        memcpy((uint8_t *)out + nbursts * burst_out, tail, 68);
+    else
+        HIPCHK(ctx, hipMemcpy((uint8_t *)out + nbursts * burst_out, tail, 68, hipMemcpyHostToDevice));
+    return MRZ_OK;
+}

@@ -552,6 +552,16 @@ __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64
     *is_long = false;
     if (op >= q) return;
     const int64_t maxf = end - q;
+    const int64_t floor_p = last_match > 0 ? last_match : 0;
+    int64_t maxb = q - floor_p;
+    if (op < maxb) maxb = op;
+    // the first backward piece is loaded together with the forward pieces: one round trip
+    uint4 rb_a = make_uint4(0, 0, 0, 0), rb_b = make_uint4(0, 0, 0, 0);
+    const bool rb_wide = maxb > 0 && op - 16 >= 0;
+    if (rb_wide) {
+        rb_a = mrz_ld16(buf + q - 16);
+        rb_b = mrz_ld16(buf + op - 16);
+    }
     int64_t fwd = 0;
     bool lng = false;
     if (maxf > 0) {
@@ -588,9 +598,6 @@ __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64
                 lng = true;
         }
     }
-    const int64_t floor_p = last_match > 0 ? last_match : 0;
-    int64_t maxb = q - floor_p;
-    if (op < maxb) maxb = op;
     int64_t rv = 0;
     if (maxb > 0 && !lng) {
         bool stop = false;
@@ -606,7 +613,9 @@ __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64
             const int64_t rem = maxb - off;
             const int lim = rem < 16 ? (int)rem : 16;
             int cnt;
-            if (op - off - 16 >= 0)
+            if (j == 0 && rb_wide)
+                cnt = mrz_top_equal16(rb_a, rb_b);
+            else if (op - off - 16 >= 0)
                 cnt = mrz_top_equal16(mrz_ld16(buf + q - off - 16), mrz_ld16(buf + op - off - 16));
             else {
                 cnt = 0;

@@ -158,6 +158,12 @@ int mrzo_lz4_compressed_size(const uint8_t *src, int n, int dst_cap);
 int mrzo_lz4_compress(const uint8_t *src, int n, uint8_t *dst, int dst_cap);
 int mrzo_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int threshold);
 
+/* ---- rs-mrzip encoder (rs-mrzip/reed-solomon.c:115-141,311-321; rs-mrzip.c:119-158) ---- */
+void mrzo_rs_parity(const uint8_t data[223], uint8_t parity[32]);
+int64_t mrzo_rs_encoded_size(int64_t n);
+int mrzo_rs_encode(const uint8_t *in, int64_t n, uint8_t *out);
+void mrzo_rs_tables(uint8_t exp_[256], uint8_t log_[256], uint8_t tal[256], uint8_t tal1[256], uint8_t gen_index[33]);
+
 #ifdef __cplusplus
 }
 #endif

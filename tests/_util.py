@@ -62,6 +62,9 @@ class Oracle:
         L.mrzo_lz4_compressed_size.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         L.mrzo_lz4_compresses.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int]
         L.mrzo_buf_free.argtypes = [ctypes.POINTER(Buf)]
+        L.mrzo_rs_encoded_size.restype = ctypes.c_int64
+        L.mrzo_rs_encoded_size.argtypes = [ctypes.c_int64]
+        L.mrzo_rs_encode.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p]
 
     @staticmethod
     def _take(L, b):
@@ -139,6 +142,16 @@ class Oracle:
 
     def lz4_compresses(self, data, threshold=100):
         return self.L.mrzo_lz4_compresses(data, len(data), threshold)
+
+    def rs_encode(self, data):
+        out = ctypes.create_string_buffer(self.L.mrzo_rs_encoded_size(len(data)))
+        assert self.L.mrzo_rs_encode(data, len(data), out) == 0
+        return out.raw
+
+    def rs_parity(self, row):
+        p = ctypes.create_string_buffer(32)
+        self.L.mrzo_rs_parity(row, p)
+        return p.raw
 
     def blake2b(self, data, outlen=64, pieces=None):
         class St(ctypes.Structure):

@@ -116,3 +116,10 @@ def test_two_chunks_through_host_driver(emu_lib, oracle):
     data = _util.rep64k(6, seed=13, period=4096)
     # ramsize chosen so that max_chunk (= ramsize/3*2, page-rounded) splits the file in two
     _parity.check_file(emu_lib, oracle, data, ramsize=3 * 16384 // 2 + 3000)
+
+
+def test_rs_encoder(emu_lib, oracle):
+    with m.RzipContext(lib=emu_lib) as ctx:
+        for n in (0, 1, 222, 223, 224, 100000):
+            d = _util.xorshift_noise(n, seed=n + 3)
+            assert ctx.rs_encode(d) == oracle.rs_encode(d), n

@@ -181,3 +181,17 @@ def test_gate_on_gpu_preprocessed_streams(gpu_lib, oracle):
         res, s0, s1 = ctx.rzip_chunk(data)
         got = ctx.lz4_compresses([s0, s1], 100)
     assert got == [oracle.lz4_compresses(s0, 100), oracle.lz4_compresses(s1, 100)]
+
+
+def test_rs_encoder(gpu_lib, oracle):
+    """rs-mrzip encode: parity + interleave on the GPU, byte-identical to the oracle
+    (itself pinned to the reference's reed-solomon.c)."""
+    import torch
+    burst = 223 * 8176
+    with m.RzipContext(lib=gpu_lib) as ctx:
+        for n in (0, 1, 223, burst - 1, burst, burst + 1, 3 * burst + 12345):
+            d = _util.xorshift_noise(n, seed=n % 977 + 3)
+            assert hashlib.sha256(ctx.rs_encode(d)).digest() == hashlib.sha256(oracle.rs_encode(d)).digest(), n
+        d = _util.zipf_text(2 * burst + 77, seed=5)
+        t = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        assert ctx.rs_encode(t) == oracle.rs_encode(d)

@@ -197,3 +197,42 @@ def test_multi_chunk_roundtrip_and_victim_round(oracle):
     b0 = o.rzip_chunk(data[len(data) // 2:], victim_round=0)
     b1 = o.rzip_chunk(data[len(data) // 2:], victim_round=a["victim_round"])
     assert a["victim_round"] != 0 or b0 == b1
+
+
+def test_rs_encoder_against_reference_build(oracle):
+    """oracle/_ref/librs_ref.so = the reference's rs-mrzip/reed-solomon.c compiled in place:
+    rse32 (parity, :115-141) and scatter (interleave, :311-321)."""
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "librs_ref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    R = ctypes.CDLL(ref_path)
+    for trial in range(64):
+        row = bytes(223) if trial == 0 else _util.xorshift_noise(223, seed=trial)
+        buf = (ctypes.c_uint8 * 255)(*row, *([0] * 32))
+        R.rse32(buf, ctypes.byref(buf, 223))
+        assert bytes(buf)[:223] == row and bytes(buf)[223:] == oracle.rs_parity(row)
+    # one whole burst through the reference's rse32 + scatter == the oracle's encoder body
+    rows, k, n = 8176, 223, 255
+    data = _util.xorshift_noise(rows * k - 1000, seed=9)
+    ec = (ctypes.c_uint8 * (rows * n))()
+    padded = data + bytes(1000)
+    for r in range(rows):
+        ctypes.memmove(ctypes.byref(ec, r * n), padded[r * k:(r + 1) * k], k)
+        R.rse32(ctypes.byref(ec, r * n), ctypes.byref(ec, r * n + k))
+    tr = (ctypes.c_uint8 * (rows * n))()
+    R.scatter(ec, tr, rows, n)
+    enc = oracle.rs_encode(data)
+    assert len(enc) == rows * n + 68
+    assert enc[: rows * n] == bytes(tr)
+    assert enc[rows * n: rows * n + 64] == hashlib.blake2b(padded).digest()
+    ki, kj = divmod(len(data), k)
+    assert enc[-4:] == bytes([ki & 255, ki >> 8, kj & 255, kj >> 8])
+
+
+def test_rs_burst_count_follows_feof(oracle):
+    """rs-mrzip.c:125: feof() only turns true after a short read, so an input that is an exact
+    multiple of a burst produces one more all-padding burst."""
+    burst = 223 * 8176
+    assert len(oracle.rs_encode(b"")) == 255 * 8176 + 68
+    assert oracle.L.mrzo_rs_encoded_size(burst - 1) == 255 * 8176 + 68
+    assert oracle.L.mrzo_rs_encoded_size(burst) == 2 * 255 * 8176 + 68
