@@ -15,9 +15,10 @@
 //   at tile end lane l still has to be advanced over the 16*(63-l) bytes that
 //   follow its final group: one GF(2) multiply by x^(128*(63-l)) mod P, then a
 //   butterfly XOR over the wave.
-// Tile results are raw (zero-init) remainders; a small second kernel advances
-// each over the bytes that follow it (multiply by x^(8*after)), XORs them, adds
-// the 0xffffffff init advanced over the whole length and complements.
+// Each wave then advances its tile remainder over the bytes that follow the tile
+// (multiply by x^(8*after), one bit of `after` per lane, butterfly product); a small
+// second kernel XORs the tiles and the byte tail, adds the 0xffffffff init advanced
+// over the whole length and complements.
 //
 // Bound: HBM read (1 B per byte); LDS table look-ups (8 per 16 B per lane) are
 // the on-chip cost.
@@ -91,7 +92,7 @@ __device__ __forceinline__ uint32_t mrz_crc_step(const uint32_t (*t)[256], uint3
 }
 
 // one wave per 64 KiB tile; parts[tile] = raw remainder of the tile
-__global__ __launch_bounds__(MRZ_CRC_THREADS) void mrz_crc_tiles_kernel(const uint8_t *__restrict__ buf,
+__global__ __launch_bounds__(MRZ_CRC_THREADS) void mrz_crc_tiles_kernel(const uint8_t *__restrict__ buf, int64_t n,
                                                                         int64_t ntiles,
                                                                         const mrz_crc_tables *__restrict__ tb,
                                                                         uint32_t *__restrict__ parts) {
@@ -114,7 +115,12 @@ __global__ __launch_bounds__(MRZ_CRC_THREADS) void mrz_crc_tiles_kernel(const ui
     }
     c = mrz_gf_mul(tb->lane_shift[lane], c);
     for (int d = 32; d >= 1; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d, MRZ_WAVE);
-    if (lane == 0) parts[tile] = c;
+    // advance the tile remainder over the bytes that follow the tile: x^(8*after) is the product of
+    // x^(2^(k+3)) over the set bits k of `after`; every lane contributes one bit, butterfly product
+    const uint64_t after = (uint64_t)(n - (tile + 1) * MRZ_CRC_TILE);
+    uint32_t f = ((after >> lane) & 1) ? tb->x2n[(lane + 3) & 31] : (1u << 31);
+    for (int d = 32; d >= 1; d >>= 1) f = mrz_gf_mul(f, (uint32_t)__shfl_xor((int)f, d, MRZ_WAVE));
+    if (lane == 0) parts[tile] = mrz_gf_mul(f, c);
 }
 
 // final combine: tiles + byte tail -> CRC-32.  One workgroup.
@@ -126,11 +132,8 @@ __global__ __launch_bounds__(MRZ_CRC_THREADS) void mrz_crc_final_kernel(const ui
     __shared__ uint32_t red[MRZ_CRC_THREADS];
     const int tid = threadIdx.x;
     uint32_t acc = 0;
-    // tiles: advance each raw remainder over the bytes that follow it
-    for (int64_t i = tid; i < ntiles; i += MRZ_CRC_THREADS) {
-        const uint64_t after = (uint64_t)(n - (i + 1) * MRZ_CRC_TILE);
-        acc ^= mrz_gf_mul(mrz_gf_xpow(tb->x2n, after, 3), parts[i]);
-    }
+    // tiles: already advanced to the end of the buffer by the tile kernel
+    for (int64_t i = tid; i < ntiles; i += MRZ_CRC_THREADS) acc ^= parts[i];
     // tail (< 64 KiB): each thread a contiguous sub-slice, bytewise
     const int64_t tail0 = ntiles * MRZ_CRC_TILE;
     const int64_t tail = n - tail0;
@@ -163,8 +166,8 @@ extern "C" hipError_t mrz_launch_crc32(hipStream_t stream, const uint8_t *buf, i
     if (ntiles > 0) {
         const int wpb = MRZ_CRC_THREADS / 64;
         const int64_t nblocks = (ntiles + wpb - 1) / wpb;
-        hipLaunchKernelGGL(mrz_crc_tiles_kernel, dim3((unsigned)nblocks), dim3(MRZ_CRC_THREADS), 0, stream, buf, ntiles,
-                           tb, parts);
+        hipLaunchKernelGGL(mrz_crc_tiles_kernel, dim3((unsigned)nblocks), dim3(MRZ_CRC_THREADS), 0, stream, buf, n,
+                           ntiles, tb, parts);
     }
     hipLaunchKernelGGL(mrz_crc_final_kernel, dim3(1), dim3(MRZ_CRC_THREADS), 0, stream, buf, n, ntiles, tb, parts,
                        crc_out);

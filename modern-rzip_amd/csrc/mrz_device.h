@@ -66,6 +66,12 @@ __device__ __forceinline__ int64_t mrz_bcast64(int64_t v, int src) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+__device__ __forceinline__ int64_t mrz_shfl_xor64(int64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)v, d, MRZ_WAVE);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), d, MRZ_WAVE);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // mask with the low `k` bits set, k in [0, 64]
 __device__ __forceinline__ mrz_u64 mrz_low_mask(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
 

@@ -126,11 +126,12 @@ __global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_write_kernel(const mr
     }
     int64_t ta, tb;
     mrz_block_scan2(c0, c1, ta, tb);
-    if (i > E) return;
+    const bool live = i <= E;
     int64_t o0 = block_s0[blockIdx.x] + c0;
     const int64_t o1 = block_s1[blockIdx.x] + c1;
-    lit_off[i] = o1;
+    if (live) lit_off[i] = o1;
     int64_t nlit = 0, nmat = 0;
+    if (!live) ll = ml = 0;
     for (int64_t rest = ll; rest > 0;) {
         const int64_t piece = rest > 0xFFFF ? 0xFFFF : rest;
         s0[o0] = 0;
@@ -151,16 +152,23 @@ __global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_write_kernel(const mr
         rest -= piece;
         nmat++;
     }
-    // statistics (st->stats.* at src/rzip.c:188-189,219-220)
-    if (nlit) {
-        atomicAdd((unsigned long long *)&totals->literals, (unsigned long long)nlit);
-        atomicAdd((unsigned long long *)&totals->literal_bytes, (unsigned long long)ll);
+    // statistics (st->stats.* at src/rzip.c:188-189,219-220): reduced over the wave first
+    {
+        int64_t v0 = nlit, v1 = nlit ? ll : 0, v2 = nmat, v3 = nmat ? ml : 0;
+        for (int d = 32; d >= 1; d >>= 1) {
+            v0 += mrz_shfl_xor64(v0, d);
+            v1 += mrz_shfl_xor64(v1, d);
+            v2 += mrz_shfl_xor64(v2, d);
+            v3 += mrz_shfl_xor64(v3, d);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (v0) atomicAdd((unsigned long long *)&totals->literals, (unsigned long long)v0);
+            if (v1) atomicAdd((unsigned long long *)&totals->literal_bytes, (unsigned long long)v1);
+            if (v2) atomicAdd((unsigned long long *)&totals->matches, (unsigned long long)v2);
+            if (v3) atomicAdd((unsigned long long *)&totals->match_bytes, (unsigned long long)v3);
+        }
     }
-    if (nmat) {
-        atomicAdd((unsigned long long *)&totals->matches, (unsigned long long)nmat);
-        atomicAdd((unsigned long long *)&totals->match_bytes, (unsigned long long)ml);
-    }
-    if (i == E) {
+    if (live && i == E) {
         // terminator literal + CRC (src/rzip.c:664-665); o0 == total s0_len here
         lit_off[E + 1] = o1 + ll;
         s0[o0] = 0;

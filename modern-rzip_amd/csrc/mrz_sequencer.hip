@@ -37,6 +37,7 @@
 // XCD's L2 / the Infinity Cache) and this CU's L1/L2 bandwidth for the match
 // extension -- not HBM bandwidth.
 #include "mrz_device.h"
+#include <stdlib.h>
 
 // cross-lane LDS exchange inside one wave: the hardware runs the lanes in lockstep, the CPU
 // emulator needs a rendezvous
@@ -80,7 +81,8 @@ enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_C
        MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED,
        MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_WALK2, MRZ_ST_T_PAIRS, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_COMMIT,
        MRZ_ST_T_SEQ, MRZ_ST_T_WINDOW, MRZ_ST_T_LONG, MRZ_ST_T_FOLD, MRZ_ST_FARMED, MRZ_ST_L_POST, MRZ_ST_L_STRIPE, MRZ_ST_L_BWD, MRZ_ST_L_WAIT,
-       MRZ_ST_L_ROUNDS, MRZ_ST_F_POST, MRZ_ST_F_WAIT, MRZ_ST_F_FOLD, MRZ_ST_F_HELPER, MRZ_ST_N };
+       MRZ_ST_L_ROUNDS, MRZ_ST_F_POST, MRZ_ST_F_WAIT, MRZ_ST_F_FOLD, MRZ_ST_F_HELPER,
+       MRZ_ST_H_FIELDS, MRZ_ST_H_FWD, MRZ_ST_H_BWD, MRZ_ST_H_DRAIN, MRZ_ST_H_ROUNDS, MRZ_ST_N };
 
 struct mrz_seq_args {
     const uint8_t *buf;
@@ -92,6 +94,7 @@ struct mrz_seq_args {
     int64_t seg_start;
     int64_t seg_len;
     void *gmailbox;           // mrz_gmailbox in device memory, zeroed by the host before every launch
+    int xcd_stride;           // blockIdx distance between working helper workgroups
 };
 
 // LDS mailbox between the leader and the helper waves: one long forward
@@ -419,6 +422,7 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #ifndef MRZ_HELPER_WGS
 #define MRZ_HELPER_WGS 16  // one workgroup per entry; spreading an entry over 4 workgroups (64 in all) measured slower
 #endif
+#define MRZ_XCD_STRIDE 8  // helper workgroup k is blockIdx (k+1)*8: same XCD (same L2) as the leader
 #define MRZ_SPIN_LIMIT (1 << 22)          // leader: ~1 s of polling for an answer that takes microseconds
 #define MRZ_HELPER_SPIN_LIMIT (1ll << 34)  // helpers: idle for as long as a launch may run
 
@@ -432,7 +436,7 @@ struct mrz_gmailbox {
     long long op[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
     long long fwd[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
     long long rev[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
-    long long dbg[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];  // helper busy time of the last job (profile builds)
+    long long dbg[5][MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];  // helper phase times of the last job (profile builds)
 };
 
 __device__ __forceinline__ long long mrz_g_load(const long long *p) {
@@ -455,12 +459,11 @@ __device__ __forceinline__ void mrz_drain_stores() {
 
 #if MRZ_HELPER_WGS > 0
 // one helper workgroup: job index = blockIdx.x - 1
-__device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailbox *g) {
+__device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailbox *g, int me) {
     __shared__ long long s_job[4];           // seq, quit
     __shared__ long long s_res[MRZ_SEQ_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = mrz_uni((int)(threadIdx.x >> 6));
-    const int me = (int)blockIdx.x - 1;
     unsigned long long seen = 0;
     while (true) {
         if (threadIdx.x == 0) {
@@ -484,11 +487,18 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
         const int64_t p0 = mrz_g_load(&g->p0), maxf = mrz_g_load(&g->maxf), floor_p = mrz_g_load(&g->maxb_floor);
         const int64_t op = mrz_g_load(&g->op[me]);
         int64_t fwd = 0;
+#ifdef MRZ_SEQ_PROFILE
+        const long long h_t1 = (long long)__builtin_amdgcn_s_memtime() + (op & 0);
+        long long h_rounds = 0;
+#endif
         if (op < p0 && maxf > 0) {
             // 8 KiB per wave and round: a 64 KiB match is one round of the workgroup
             for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * 8192) {
                 const int64_t r = mrz_wave_fwd_stripe_n<8>(buf, p0, op, maxf, base + (int64_t)wave * 8192, lane);
                 if (lane == 0) s_res[wave] = r;
+#ifdef MRZ_SEQ_PROFILE
+                h_rounds++;
+#endif
                 __syncthreads();
                 int64_t best = -1;
                 for (int w = 0; w < MRZ_SEQ_WAVES && best < 0; w++) best = s_res[w];
@@ -501,16 +511,28 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
         }
         if (wave == 0) {
             int64_t rev = 0;
+#ifdef MRZ_SEQ_PROFILE
+            const long long h_t2 = (long long)__builtin_amdgcn_s_memtime() + (fwd & 0);
+#endif
             if (op < p0) {
                 int64_t maxb = p0 - floor_p;
                 if (op < maxb) maxb = op;
                 rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
             }
             if (lane == 0) {
+#ifdef MRZ_SEQ_PROFILE
+                const long long h_t3 = (long long)__builtin_amdgcn_s_memtime() + (rev & 0);
+#endif
                 mrz_g_store(&g->fwd[me], op < p0 ? fwd : -1);
                 mrz_g_store(&g->rev[me], rev);
 #ifdef MRZ_SEQ_PROFILE
-                mrz_g_store(&g->dbg[me], (long long)__builtin_amdgcn_s_memtime() - h_t0);
+                mrz_drain_stores();
+                const long long h_t4 = (long long)__builtin_amdgcn_s_memtime();
+                mrz_g_store(&g->dbg[0][me], h_t1 - h_t0);
+                mrz_g_store(&g->dbg[1][me], h_t2 - h_t1);
+                mrz_g_store(&g->dbg[2][me], h_t3 - h_t2);
+                mrz_g_store(&g->dbg[3][me], h_t4 - h_t3);
+                mrz_g_store(&g->dbg[4][me], h_rounds);
 #endif
                 mrz_drain_stores();
                 __hip_atomic_fetch_add(&g->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -780,6 +802,19 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
             farmed = true;
             stat[MRZ_ST_FARMED] += 1;
             PROF_ADD(MRZ_ST_F_WAIT);
+#ifdef MRZ_SEQ_PROFILE
+            {   // phases of the helper that took longest
+                int worst = 0;
+                long long wt = -1;
+                for (int k = 0; k < nsx; k++) {
+                    if (mrz_uni(B->pair_res[row][k]) >= 0) continue;
+                    long long tt = 0;
+                    for (int ph = 0; ph < 4; ph++) tt += mrz_g_load(&g->dbg[ph][k]);
+                    if (tt > wt) { wt = tt; worst = k; }
+                }
+                for (int ph = 0; ph < 5; ph++) stat[MRZ_ST_H_FIELDS + ph] += mrz_g_load(&g->dbg[ph][worst]);
+            }
+#endif
             // every lane fetches one entry's answer (one round trip for all of them)
             int64_t my_fw = 0, my_rv = 0, my_op = 0;
             int my_r = 0;
@@ -1442,7 +1477,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     if (st->finished || st->error) return;
 #if MRZ_HELPER_WGS > 0
     if (blockIdx.x != 0) {
-        mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
+        // workgroups are dealt to the 8 XCDs round-robin: with a stride of 8 only the ones that land on the
+        // leader's XCD (and share its L2) work, the others leave at once
+        if (blockIdx.x % a.xcd_stride == 0) mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox, (int)(blockIdx.x / a.xcd_stride) - 1);
         return;
     }
 #endif
@@ -1650,11 +1687,18 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     a.seg_start = seg_start;
     a.seg_len = seg_len;
     a.gmailbox = gmailbox;
+    static int stride = 0;
+    if (!stride) {
+        const char *e = getenv("MRZ_XCD_STRIDE");
+        stride = e ? atoi(e) : MRZ_XCD_STRIDE;
+        if (stride < 1 || stride > 64) stride = MRZ_XCD_STRIDE;
+    }
+    a.xcd_stride = stride;
     if (gmailbox) {
         hipError_t e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1 + (gmailbox ? MRZ_HELPER_WGS : 0)), dim3(MRZ_SEQ_THREADS), 0, stream,
+    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1 + (gmailbox ? MRZ_HELPER_WGS * stride : 0)), dim3(MRZ_SEQ_THREADS), 0, stream,
                        a);
     return hipGetLastError();
 }
