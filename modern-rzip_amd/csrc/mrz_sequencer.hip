@@ -94,7 +94,7 @@ struct mrz_seq_args {
     int64_t seg_start;
     int64_t seg_len;
     void *gmailbox;           // mrz_gmailbox in device memory, zeroed by the host before every launch
-    int xcd_stride;           // blockIdx distance between working helper workgroups
+    int n_helpers;            // helper workgroups in this launch (grid size - 1)
 };
 
 // LDS mailbox between the leader and the helper waves: one long forward
@@ -202,7 +202,7 @@ __device__ static int64_t mrz_wave_bwd(const uint8_t *__restrict__ buf, int64_t 
 // the backward extension while the helpers are busy with the first round.
 __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int *mb_seq, int64_t p0,
                                              int64_t op, int64_t end, int64_t last_match, int64_t *rev_out, int lane,
-                                             int64_t *stat = nullptr) {
+                                             int64_t *stat = nullptr, int64_t *cont_base = nullptr) {
     *rev_out = 0;
 #ifdef MRZ_SEQ_PROFILE
     int64_t lt0 = (int64_t)__builtin_amdgcn_s_memtime();
@@ -254,6 +254,11 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
             if (best >= 0) {
                 fwd = best;
                 break;
+            }
+            if (cont_base) {  // the caller continues from here (compare farm); returns -1
+                *cont_base = base + (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE;
+                *rev_out = rev;
+                return -1;
             }
         }
     }
@@ -408,135 +413,125 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
     }
 }
 
-// ---- helper workgroups on other CUs ------------------------------------------------------
+// ---- the compare farm: helper workgroups on the other CUs ---------------------------------
 // A look-up on repetitive input can find max_chain_len tag-equal entries that are ALL tens of
-// KiB long (every earlier copy of the same text): ~1 MB to compare for one candidate, which is
-// what one CU can pull through its L1/L2 in ~15 us.  The compares are independent, so the grid
-// carries MRZ_HELPER_WGS extra workgroups (one per CU: 512 threads x 256 VGPRs fill a CU) that
-// wait on a mailbox in device memory; the leader hands each of them one entry.
-// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms"): every handed-off word is written with
-// an agent-scope atomic store (write-through, sc1) and read with an agent-scope atomic load
-// (sc1); every storing wave drains (s_waitcnt vmcnt(0)) before the flag / counter update; flags
-// are polled with relaxed agent-scope loads and s_sleep.  The compared bytes themselves are
-// read-only input.  All spins are bounded.
+// KiB long (every earlier copy of the same text): megabytes to compare for one candidate.  One
+// CU keeps only ~8 KiB of loads in flight (~20 GB/s on cold data), so the compares are spread
+// over the whole chip: the grid carries helper workgroups (one per CU: 512 threads x 256 VGPRs
+// fill a CU) that wait on a mailbox in device memory.  A round compares, for every pending
+// entry e, G consecutive 16 KiB stripes: helper w = e*G + s takes stripe s of entry e (2 KiB
+// per wave) and reports where the compare stops inside its stripe, or "equal throughout".
+//
+// Hand-off protocol.  Every mailbox word carries the round number in its top 24 bits and the
+// payload (an offset < 2^40) in the low 40, is written with ONE agent-scope (sc1) atomic store
+// and read with an agent-scope atomic load, so no ordering between words is needed: the reader
+// polls until every word it needs shows the round it waits for.  The leader writes the whole
+// job descriptor with one store instruction (24 lanes), a helper fetches it with one load
+// instruction; results come back the same way, one word per helper.  The mailbox is zeroed by
+// the host before every launch and a launch runs fewer than 2^24 rounds, so a tag never
+// repeats.  Helpers take a ticket when they start; the leader only addresses tickets it has
+// seen, so the scheme does not depend on every workgroup of the grid being resident.  The
+// compared bytes themselves are read-only input.  All spins are bounded.
 #ifndef MRZ_HELPER_WGS
-#define MRZ_HELPER_WGS 16  // one workgroup per entry; spreading an entry over 4 workgroups (64 in all) measured slower
+#define MRZ_HELPER_WGS 240  // most of the 256 CUs; the launcher may ask for fewer
 #endif
-#define MRZ_XCD_STRIDE 8  // helper workgroup k is blockIdx (k+1)*8: same XCD (same L2) as the leader
+#define MRZ_FARM_ENTRIES 16
+#define MRZ_FARM_WAVE_BYTES 2048
+#define MRZ_FARM_SPW (MRZ_SEQ_WAVES * MRZ_FARM_WAVE_BYTES)  // bytes of each stream per helper and round
+#define MRZ_FARM_GMAX 32
+#define MRZ_FARM_SHIFT 40
+#define MRZ_FARM_PAYLOAD ((1ull << MRZ_FARM_SHIFT) - 1)
+#define MRZ_FARM_NONE MRZ_FARM_PAYLOAD
 #define MRZ_SPIN_LIMIT (1 << 22)          // leader: ~1 s of polling for an answer that takes microseconds
 #define MRZ_HELPER_SPIN_LIMIT (1ll << 34)  // helpers: idle for as long as a launch may run
 
 struct mrz_gmailbox {
-    unsigned long long seq;          // bumped by the leader per job round
-    unsigned long long quit;
-    unsigned long long done;         // helpers add 1 per finished job
-    unsigned long long njobs;
-    long long p0, maxf, maxb_floor;  // compare buf[p0+x] / buf[op+x], x < maxf; backward floor = max(0,last_match)
-    long long pad0;
-    long long op[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
-    long long fwd[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
-    long long rev[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];
-    long long dbg[5][MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];  // helper phase times of the last job (profile builds)
+    unsigned long long quit;   // set by the leader when the launch is over
+    unsigned long long ready;  // ticket counter: helpers that have started
+    unsigned long long pad0[14];
+    // job descriptor: 0 p0, 1 maxf, 2 backward floor, 3 base, 4 nsx | G << 8 | want_rev << 16, 5-7 spare,
+    // 8.. entry offsets (an offset >= p0 means "not pending")
+    unsigned long long words[8 + MRZ_FARM_ENTRIES];
+    unsigned long long pad1[8];
+    unsigned long long rev[MRZ_FARM_ENTRIES];                          // backward length per entry
+    unsigned long long res[MRZ_HELPER_WGS > 0 ? MRZ_HELPER_WGS : 1];   // forward stop per helper, or NONE
+    long long dbg[5][MRZ_FARM_ENTRIES];                                // helper phase times (profile builds)
 };
 
-__device__ __forceinline__ long long mrz_g_load(const long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ unsigned long long mrz_g_loadu(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void mrz_g_store(long long *p, long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void mrz_g_storeu(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void mrz_drain_stores() {
-#ifdef __HIP_DEVICE_COMPILE__
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
 
 #if MRZ_HELPER_WGS > 0
-// one helper workgroup: job index = blockIdx.x - 1
-__device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailbox *g, int me) {
-    __shared__ long long s_job[4];           // seq, quit
+__device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailbox *g) {
+    __shared__ unsigned long long s_job[26];
     __shared__ long long s_res[MRZ_SEQ_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = mrz_uni((int)(threadIdx.x >> 6));
+    if (threadIdx.x == 0)
+        s_job[25] = __hip_atomic_fetch_add(&g->ready, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int me = (int)s_job[25];  // my ticket
     unsigned long long seen = 0;
+    if (me >= MRZ_HELPER_WGS) return;
     while (true) {
-        if (threadIdx.x == 0) {
-            unsigned long long s = seen;
+        if (wave == 0) {
             long long spins = 0;
-            while ((s = mrz_g_loadu(&g->seq)) == seen && spins++ < MRZ_HELPER_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
-            s_job[0] = (long long)s;
-            s_job[1] = (s == seen) ? 1 : (long long)mrz_g_loadu(&g->quit);  // spin limit => give up
+            while (true) {
+                unsigned long long w = 0;
+                if (lane < 8 + MRZ_FARM_ENTRIES)
+                    w = mrz_g_loadu(&g->words[lane]);
+                else if (lane == 8 + MRZ_FARM_ENTRIES)
+                    w = mrz_g_loadu(&g->quit);
+                const unsigned long long tag = w >> MRZ_FARM_SHIFT;
+                const unsigned long long tag0 = (unsigned long long)mrz_bcast64((int64_t)tag, 0);
+                const bool quit = mrz_bcast64((int64_t)w, 8 + MRZ_FARM_ENTRIES) != 0;
+                const bool fresh = tag0 != seen && __ballot(lane < 8 + MRZ_FARM_ENTRIES && tag != tag0) == 0;
+                const bool giveup = quit || spins++ >= MRZ_HELPER_SPIN_LIMIT;
+                if (fresh || giveup) {
+                    if (lane < 8 + MRZ_FARM_ENTRIES) s_job[lane] = w & MRZ_FARM_PAYLOAD;
+                    if (lane == 8 + MRZ_FARM_ENTRIES) s_job[lane] = giveup ? ~0ull : tag0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
         }
         __syncthreads();
-        const unsigned long long s = (unsigned long long)s_job[0];
-        const bool quit = s_job[1] != 0;
+        const unsigned long long tag = s_job[8 + MRZ_FARM_ENTRIES];
+        const int64_t p0 = (int64_t)s_job[0], maxf = (int64_t)s_job[1], floor_p = (int64_t)s_job[2];
+        const int64_t base = (int64_t)s_job[3];
+        const int cfg = (int)s_job[4];
+        const int nsx = cfg & 0xff, G = (cfg >> 8) & 0xff;
+        const bool want_rev = (cfg >> 16) & 1;
+        const int e = G ? me / G : nsx, s = G ? me % G : 0;
+        const int64_t op = e < nsx ? (int64_t)s_job[8 + (e & (MRZ_FARM_ENTRIES - 1))] : p0;
         __syncthreads();
-        if (quit) return;
-        seen = s;
+        if (tag == ~0ull) return;
+        seen = tag;
+        if (e >= nsx || op >= p0) continue;
 #ifdef MRZ_SEQ_PROFILE
         const long long h_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
-        const int nj = (int)mrz_g_loadu(&g->njobs);
-        if (me >= nj) continue;
-        const int64_t p0 = mrz_g_load(&g->p0), maxf = mrz_g_load(&g->maxf), floor_p = mrz_g_load(&g->maxb_floor);
-        const int64_t op = mrz_g_load(&g->op[me]);
-        int64_t fwd = 0;
-#ifdef MRZ_SEQ_PROFILE
-        const long long h_t1 = (long long)__builtin_amdgcn_s_memtime() + (op & 0);
-        long long h_rounds = 0;
-#endif
-        if (op < p0 && maxf > 0) {
-            // 8 KiB per wave and round: a 64 KiB match is one round of the workgroup
-            for (int64_t base = 0;; base += (int64_t)MRZ_SEQ_WAVES * 8192) {
-                const int64_t r = mrz_wave_fwd_stripe_n<8>(buf, p0, op, maxf, base + (int64_t)wave * 8192, lane);
-                if (lane == 0) s_res[wave] = r;
-#ifdef MRZ_SEQ_PROFILE
-                h_rounds++;
-#endif
-                __syncthreads();
-                int64_t best = -1;
-                for (int w = 0; w < MRZ_SEQ_WAVES && best < 0; w++) best = s_res[w];
-                __syncthreads();
-                if (best >= 0) {
-                    fwd = best;
-                    break;
-                }
-            }
+        const int64_t off0 = base + (int64_t)s * MRZ_FARM_SPW + (int64_t)wave * MRZ_FARM_WAVE_BYTES;
+        const int64_t r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf, off0, lane);
+        if (lane == 0) s_res[wave] = r;
+        if (wave == MRZ_SEQ_WAVES - 1 && s == 0 && want_rev) {
+            int64_t maxb = p0 - floor_p;
+            if (op < maxb) maxb = op;
+            const int64_t rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
+            if (lane == 0) mrz_g_storeu(&g->rev[e], (tag << MRZ_FARM_SHIFT) | (unsigned long long)rev);
         }
-        if (wave == 0) {
-            int64_t rev = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t best = -1;
+            for (int w = 0; w < MRZ_SEQ_WAVES && best < 0; w++) best = s_res[w];
+            mrz_g_storeu(&g->res[me], (tag << MRZ_FARM_SHIFT) | (best < 0 ? MRZ_FARM_NONE : (unsigned long long)best));
 #ifdef MRZ_SEQ_PROFILE
-            const long long h_t2 = (long long)__builtin_amdgcn_s_memtime() + (fwd & 0);
+            if (s == 0) g->dbg[1][e] = (long long)__builtin_amdgcn_s_memtime() - h_t0;
 #endif
-            if (op < p0) {
-                int64_t maxb = p0 - floor_p;
-                if (op < maxb) maxb = op;
-                rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
-            }
-            if (lane == 0) {
-#ifdef MRZ_SEQ_PROFILE
-                const long long h_t3 = (long long)__builtin_amdgcn_s_memtime() + (rev & 0);
-#endif
-                mrz_g_store(&g->fwd[me], op < p0 ? fwd : -1);
-                mrz_g_store(&g->rev[me], rev);
-#ifdef MRZ_SEQ_PROFILE
-                mrz_drain_stores();
-                const long long h_t4 = (long long)__builtin_amdgcn_s_memtime();
-                mrz_g_store(&g->dbg[0][me], h_t1 - h_t0);
-                mrz_g_store(&g->dbg[1][me], h_t2 - h_t1);
-                mrz_g_store(&g->dbg[2][me], h_t3 - h_t2);
-                mrz_g_store(&g->dbg[3][me], h_t4 - h_t3);
-                mrz_g_store(&g->dbg[4][me], h_rounds);
-#endif
-                mrz_drain_stores();
-                __hip_atomic_fetch_add(&g->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
 }
@@ -557,6 +552,7 @@ struct mrz_batch_lds {
     int same_slot[64][MRZ_SMAX];
     int pair_res[64][MRZ_SMAX];  // (len << 8) | rev, or -1 = needs the cooperative path
     unsigned filter[MRZ_FILTER_SIZE];
+    unsigned long long farm_min[16];  // per entry: lowest stop offset any helper reported
 };
 
 
@@ -681,6 +677,9 @@ struct mrz_cfg {
     int64_t end, limit, max_chain, slot_mask, nslots, event_cap;
     mrz_gmailbox *gmb;
     unsigned long long *gseq;  // leader's copy of the global round counter
+    int *gnw;                  // helper tickets the leader has seen so far
+    int n_helpers;             // helper workgroups in this launch
+    int64_t *farm_hint;        // forward length of the last long match: go to the farm at once when it was big
 };
 
 // lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
@@ -750,122 +749,202 @@ __device__ static void mrz_cull_one(const mrz_cfg &C, mrz_lead &L, int lane) {
     }
 }
 
+#if MRZ_HELPER_WGS > 0
+// Farm rounds for the pending entries of one look-up at p0.  Lane e (< nsx <= 16) passes its entry in my_op /
+// my_pending.  Rounds continue from offset `base` until every pending entry has hit its first difference (or maxf);
+// on return lane e holds the forward stop offset (from p0) in *my_fwd and, with want_rev, the backward length in
+// *my_rev.  Needs *C.gnw >= nsx helpers.
+__device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, int64_t maxf, int64_t floor_p,
+                                int64_t base, int nsx, int64_t my_op, bool my_pending, bool want_rev, int lane,
+                                int64_t *stat, int64_t *my_fwd, int64_t *my_rev) {
+    mrz_gmailbox *g = C.gmb;
+#ifdef MRZ_SEQ_PROFILE
+    int64_t prof_t0 = (int64_t)__builtin_amdgcn_s_memtime();
+#endif
+    mrz_u64 pending = __ballot(my_pending && lane < nsx);
+    int64_t fwd = 0, rev = 0;
+    while (pending) {
+        const int nw = *C.gnw;
+        int G = nw / nsx;
+        if (G > MRZ_FARM_GMAX) G = MRZ_FARM_GMAX;
+        const int nass = nsx * G;
+        *C.gseq += 1;
+        const unsigned long long seq = *C.gseq;
+        // post: one store instruction carries the whole job
+        {
+            const int src = (lane - 8) & 63;
+            const int64_t op_of = __shfl(my_op, src, MRZ_WAVE);
+            unsigned long long v = 0;
+            if (lane == 0) v = (unsigned long long)p0;
+            if (lane == 1) v = (unsigned long long)(maxf > 0 ? maxf : 0);
+            if (lane == 2) v = (unsigned long long)floor_p;
+            if (lane == 3) v = (unsigned long long)base;
+            if (lane == 4) v = (unsigned long long)(nsx | (G << 8) | ((want_rev ? 1 : 0) << 16));
+            if (lane >= 8) v = (unsigned long long)((src < nsx && ((pending >> src) & 1)) ? op_of : p0);
+            if (lane < 8 + MRZ_FARM_ENTRIES) mrz_g_storeu(&g->words[lane], (seq << MRZ_FARM_SHIFT) | v);
+        }
+        PROF_ADD(MRZ_ST_F_POST);
+        // which result words this lane watches
+        int ent[4];
+        bool watch[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int w = lane + 64 * j;
+            ent[j] = w / G;
+            watch[j] = w < nass && ((pending >> (ent[j] & 63)) & 1);
+        }
+        const bool watch_rev = want_rev && lane < nsx && ((pending >> lane) & 1);
+        unsigned long long val[4] = { 0, 0, 0, 0 }, rv = 0, ready = 0;
+        int spins = 0;
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (watch[j]) val[j] = mrz_g_loadu(&g->res[lane + 64 * j]);
+            if (watch_rev) rv = mrz_g_loadu(&g->rev[lane]);
+            if (lane == 63) ready = mrz_g_loadu(&g->ready);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (watch[j]) ok = ok && (val[j] >> MRZ_FARM_SHIFT) == seq;
+            if (watch_rev) ok = ok && (rv >> MRZ_FARM_SHIFT) == seq;
+            if (__ballot(!ok) == 0) break;
+            if (spins++ >= MRZ_SPIN_LIMIT) {
+                if (lane == 0) C.st->error = 3;  // helpers never answered
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        {
+            int seen = (int)mrz_bcast64((int64_t)ready, 63);
+            if (seen > C.n_helpers) seen = C.n_helpers;
+            if (seen > *C.gnw) *C.gnw = seen;
+        }
+        PROF_ADD(MRZ_ST_F_WAIT);
+        stat[MRZ_ST_FARMED] += 1;
+        // fold: the stop of entry e is the lowest offset any of its stripes reported
+        if (lane < MRZ_FARM_ENTRIES) B->farm_min[lane] = MRZ_FARM_NONE;
+        MRZ_WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long off = val[j] & MRZ_FARM_PAYLOAD;
+            if (watch[j] && off != MRZ_FARM_NONE) atomicMin(&B->farm_min[ent[j]], off);
+        }
+        MRZ_WAVE_SYNC();
+        const unsigned long long m = lane < MRZ_FARM_ENTRIES ? B->farm_min[lane] : MRZ_FARM_NONE;
+        const bool mine = lane < nsx && ((pending >> lane) & 1);
+        const bool resolved = mine && m != MRZ_FARM_NONE;
+        if (resolved) fwd = (int64_t)m;
+        if (watch_rev) rev = (int64_t)(rv & MRZ_FARM_PAYLOAD);
+        pending &= ~__ballot(resolved);
+        base += (int64_t)G * MRZ_FARM_SPW;
+        want_rev = false;
+        PROF_ADD(MRZ_ST_F_FOLD);
+    }
+    *my_fwd = fwd;
+    *my_rev = rev;
+    return true;
+}
+
+// refresh the count of helpers that have started (only until all of them have)
+__device__ __forceinline__ void mrz_farm_census(const mrz_cfg &C) {
+    if (C.gmb && *C.gnw < C.n_helpers) {
+        int seen = (int)mrz_uni64((int64_t)mrz_g_loadu(&C.gmb->ready));
+        if (seen > C.n_helpers) seen = C.n_helpers;
+        *C.gnw = seen;
+    }
+}
+#endif
+
 // Exact evaluation of up to MRZ_SMAX tag-equal entries of ONE candidate at position qx:
 // B->same_off[row][k] are the entries in probe order, B->pair_res[row][k] their per-lane
 // results ((len << 8) | rev, or -1 when an extension ran past the 64-byte reach).  Long
-// entries are extended by helper workgroups on other CUs (two or more of them) or by this
-// workgroup's striped path; then everything is folded in probe order (first longest wins,
+// entries are extended by the compare farm (two or more of them, or one when the last long
+// match was big) or by this workgroup's striped path, which hands over to the farm after its
+// first round; then everything is folded in probe order (first longest wins,
 // src/rzip.c:446-450).  Accumulates into *xb/*xoff/*xrev/*xh/*xm.
 __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_batch_lds *B, mrz_mailbox *mb,
                                            int *mb_seq, int64_t qx, int nsx, int row, int lane, int64_t *stat,
                                            int64_t *xb, int64_t *xoff, int64_t *xrev, int *xh, int *xm) {
     const uint8_t *__restrict__ buf = C.buf;
+    int my_r = 0;            // lane k: result of entry k
+    int64_t my_op = 0, my_ml = 0, my_rv = 0;
+    if (lane < nsx) {
+        my_r = B->pair_res[row][lane];
+        my_op = B->same_off[row][lane];
+    }
+    const mrz_u64 longmask = __ballot(lane < nsx && my_r < 0);
+    const int nlong = __popcll(longmask);
+    const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
     bool farmed = false;
-#ifdef MRZ_SEQ_PROFILE
-    int64_t prof_t0 = (int64_t)__builtin_amdgcn_s_memtime();
-#endif
 #if MRZ_HELPER_WGS > 0
-    {
-        int nlong = 0;
-        for (int k = 0; k < nsx; k++)
-            if (mrz_uni(B->pair_res[row][k]) < 0) nlong++;
-        if (nlong >= 2 && nsx <= MRZ_HELPER_WGS && C.gmb) {
-            // hand every long entry to its own helper workgroup
-            mrz_gmailbox *g = C.gmb;
-            if (lane < nsx) {
-                // entries that are not long get an offset >= p0, which a helper answers with -1 at once
-                const bool is_long = B->pair_res[row][lane] < 0;
-                mrz_g_store(&g->op[lane], is_long ? (long long)B->same_off[row][lane] : (long long)qx);
-            }
-            if (lane == 0) {
-                const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
-                mrz_g_store(&g->p0, qx);
-                mrz_g_store(&g->maxf, C.end - qx);
-                mrz_g_store(&g->maxb_floor, floor_p);
-                mrz_g_storeu(&g->njobs, (unsigned long long)nsx);
-                mrz_g_storeu(&g->done, 0ull);
-            }
-            mrz_drain_stores();
-            *C.gseq += 1;
-            if (lane == 0) mrz_g_storeu(&g->seq, *C.gseq);
-            PROF_ADD(MRZ_ST_F_POST);
-            int spins = 0;
-            bool arrived = false;
-            while (!arrived && spins++ < MRZ_SPIN_LIMIT) {
-                arrived = mrz_uni((int)mrz_g_loadu(&g->done)) >= nsx;
-                if (!arrived) __builtin_amdgcn_s_sleep(2);
-            }
-            if (!arrived) {
-                if (lane == 0) C.st->error = 3;  // helpers never answered
+    if (nlong && C.gmb && nsx <= MRZ_FARM_ENTRIES) {
+        mrz_farm_census(C);
+        if (*C.gnw >= nsx && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
+            int64_t fw, rv;
+            if (!mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
+                          &rv))
                 return false;
+            if (my_r < 0) {
+                my_ml = my_op < qx ? fw + rv : 0;
+                my_rv = rv;
+                if (my_ml < MRZ_MIN_MATCH) my_ml = 0;
             }
             farmed = true;
-            stat[MRZ_ST_FARMED] += 1;
-            PROF_ADD(MRZ_ST_F_WAIT);
-#ifdef MRZ_SEQ_PROFILE
-            {   // phases of the helper that took longest
-                int worst = 0;
-                long long wt = -1;
-                for (int k = 0; k < nsx; k++) {
-                    if (mrz_uni(B->pair_res[row][k]) >= 0) continue;
-                    long long tt = 0;
-                    for (int ph = 0; ph < 4; ph++) tt += mrz_g_load(&g->dbg[ph][k]);
-                    if (tt > wt) { wt = tt; worst = k; }
-                }
-                for (int ph = 0; ph < 5; ph++) stat[MRZ_ST_H_FIELDS + ph] += mrz_g_load(&g->dbg[ph][worst]);
-            }
-#endif
-            // every lane fetches one entry's answer (one round trip for all of them)
-            int64_t my_fw = 0, my_rv = 0, my_op = 0;
-            int my_r = 0;
-            if (lane < nsx) {
-                my_r = B->pair_res[row][lane];
-                my_op = B->same_off[row][lane];
-                if (my_r < 0) {
-                    my_fw = mrz_g_load(&g->fwd[lane]);
-                    my_rv = mrz_g_load(&g->rev[lane]);
-                }
-            }
-            for (int k = 0; k < nsx; k++) {
-                const int r = mrz_lane_read(my_r, k);
-                const int64_t op = mrz_bcast64(my_op, k);
-                int64_t ml, rv;
-                if (r < 0) {
-                    const int64_t fw = mrz_bcast64(my_fw, k);
-                    rv = mrz_bcast64(my_rv, k);
-                    ml = fw + rv;
-                    if (fw < 0 || ml < MRZ_MIN_MATCH) ml = 0;
-                } else {
-                    ml = r >> 8;
-                    rv = r & 0xff;
-                }
-                if (ml) {
-                    if (ml > *xb) {
-                        *xb = ml;
-                        *xoff = op - rv;
-                        *xrev = rv;
-                    }
-                    *xh += 1;
-                } else
-                    *xm += 1;
-            }
         }
     }
 #endif
-    for (int k = 0; k < nsx && !farmed; k++) {
-        const int r = mrz_uni(B->pair_res[row][k]);
-        const int64_t op = mrz_uni64(B->same_off[row][k]);
-        int64_t ml, rv;
-        if (r < 0)
-            ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat);
-        else {
-            ml = r >> 8;
-            rv = r & 0xff;
+    if (!farmed) {
+        for (int k = 0; k < nsx; k++) {
+            if (!((longmask >> k) & 1)) continue;
+            const int64_t op = mrz_bcast64(my_op, k);
+            int64_t rv = 0, cont = 0;
+            int64_t ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat,
+#if MRZ_HELPER_WGS > 0
+                                            (C.gmb && *C.gnw >= 1) ? &cont : nullptr
+#else
+                                            nullptr
+#endif
+            );
+#if MRZ_HELPER_WGS > 0
+            if (ml < 0) {
+                // still equal after the local round: the rest of the forward compare goes to the farm
+                int64_t fw, dummy;
+                if (!mrz_farm(C, B, qx, C.end - qx, floor_p, cont, 1, op, true, false, lane, stat, &fw, &dummy))
+                    return false;
+                fw = mrz_bcast64(fw, 0);
+                ml = fw + rv;
+                if (ml < MRZ_MIN_MATCH) ml = 0;
+            }
+#endif
+            if (lane == k) {
+                my_ml = ml;
+                my_rv = rv;
+            }
         }
+    }
+    if (lane < nsx && my_r >= 0) {
+        my_ml = my_r >> 8;
+        my_rv = my_r & 0xff;
+    }
+#if MRZ_HELPER_WGS > 0
+    if (nlong) {
+        // remember how far long matches reach here (decides farm-first for single long entries)
+        int64_t far = 0;
+        for (int k = 0; k < nsx; k++)
+            if ((longmask >> k) & 1) {
+                const int64_t v = mrz_bcast64(my_ml, k);
+                if (v > far) far = v;
+            }
+        *C.farm_hint = far;
+    }
+#endif
+    for (int k = 0; k < nsx; k++) {
+        const int64_t ml = mrz_bcast64(my_ml, k);
         if (ml) {
             if (ml > *xb) {
+                const int64_t rv = mrz_bcast64(my_rv, k);
                 *xb = ml;
-                *xoff = op - rv;
+                *xoff = mrz_bcast64(my_op, k) - rv;
                 *xrev = rv;
             }
             *xh += 1;
@@ -1477,9 +1556,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     if (st->finished || st->error) return;
 #if MRZ_HELPER_WGS > 0
     if (blockIdx.x != 0) {
-        // workgroups are dealt to the 8 XCDs round-robin: with a stride of 8 only the ones that land on the
-        // leader's XCD (and share its L2) work, the others leave at once
-        if (blockIdx.x % a.xcd_stride == 0) mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox, (int)(blockIdx.x / a.xcd_stride) - 1);
+        mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
         return;
     }
 #endif
@@ -1527,6 +1604,11 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     C.gmb = (mrz_gmailbox *)a.gmailbox;
     unsigned long long gseq = 0;
     C.gseq = &gseq;
+    int gnw = 0;
+    C.gnw = &gnw;
+    C.n_helpers = a.n_helpers;
+    int64_t farm_hint = 0;
+    C.farm_hint = &farm_hint;
     mrz_lead L;
     L.p = st->p;
     L.cur_p = st->cur_p;
@@ -1646,11 +1728,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 
     // release the helpers, then publish the state for the next segment's launch
 #if MRZ_HELPER_WGS > 0
-    if (lane == 0 && C.gmb) {
-        mrz_g_storeu(&C.gmb->quit, 1ull);
-        mrz_drain_stores();
-        mrz_g_storeu(&C.gmb->seq, gseq + 1);
-    }
+    if (lane == 0 && C.gmb) mrz_g_storeu(&C.gmb->quit, 1ull);
 #endif
     if (lane == 0) {
         mrz_mb_store(&mb->quit, 1);
@@ -1687,18 +1765,27 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     a.seg_start = seg_start;
     a.seg_len = seg_len;
     a.gmailbox = gmailbox;
-    static int stride = 0;
-    if (!stride) {
-        const char *e = getenv("MRZ_XCD_STRIDE");
-        stride = e ? atoi(e) : MRZ_XCD_STRIDE;
-        if (stride < 1 || stride > 64) stride = MRZ_XCD_STRIDE;
+    static int n_helpers = -1;
+#if MRZ_HELPER_WGS == 0
+    n_helpers = 0;
+#else
+    if (n_helpers < 0) {
+        int cus = 0, dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n_helpers = cus > 16 ? cus - 16 : 0;  // the leader's CU and a few for co-resident kernels stay free
+        const char *e = getenv("MRZ_FARM_WGS");
+        if (e) n_helpers = atoi(e);
+        if (n_helpers > MRZ_HELPER_WGS) n_helpers = MRZ_HELPER_WGS;
+        if (n_helpers < 0) n_helpers = 0;
     }
-    a.xcd_stride = stride;
+#endif
+    a.n_helpers = gmailbox ? n_helpers : 0;
     if (gmailbox) {
         hipError_t e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1 + (gmailbox ? MRZ_HELPER_WGS * stride : 0)), dim3(MRZ_SEQ_THREADS), 0, stream,
+    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1 + a.n_helpers), dim3(MRZ_SEQ_THREADS), 0, stream,
                        a);
     return hipGetLastError();
 }
