@@ -430,12 +430,12 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->hash_count = hs.count;
     res->n_events = E;
     if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[37] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
+        static const char *names[40] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
                                          "cut_cull", "batch_emits", "cut_cascade", "pairs", "formed", "t_form", "t_walk",
                                          "t_walk2", "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window", "t_long",
                                          "t_fold", "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait", "f_fold",
-                                         "f_helper_max", "h_fields", "h_fwd", "h_bwd", "h_drain", "h_rounds" };
-        for (int k = 0; k < 37; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
+                                         "f_helper_max", "h_fields", "h_fwd", "h_bwd", "h_drain", "h_rounds", "s_tab", "s_pair", "s_ins" };
+        for (int k = 0; k < 40; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

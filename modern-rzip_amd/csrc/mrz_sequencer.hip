@@ -65,6 +65,7 @@
 // optional in-kernel cycle accounting (diagnostic builds only: -DMRZ_SEQ_PROFILE)
 #ifdef MRZ_SEQ_PROFILE
 #define PROF_T0() int64_t prof_t0 = (int64_t)__builtin_amdgcn_s_memtime()
+#define PROF_T0R() prof_t0 = (int64_t)__builtin_amdgcn_s_memtime()
 #define PROF_ADD(k)                                                      \
     do {                                                                 \
         const int64_t now__ = (int64_t)__builtin_amdgcn_s_memtime();     \
@@ -73,6 +74,7 @@
     } while (0)
 #else
 #define PROF_T0()
+#define PROF_T0R()
 #define PROF_ADD(k)
 #endif
 
@@ -82,7 +84,8 @@ enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_C
        MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_WALK2, MRZ_ST_T_PAIRS, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_COMMIT,
        MRZ_ST_T_SEQ, MRZ_ST_T_WINDOW, MRZ_ST_T_LONG, MRZ_ST_T_FOLD, MRZ_ST_FARMED, MRZ_ST_L_POST, MRZ_ST_L_STRIPE, MRZ_ST_L_BWD, MRZ_ST_L_WAIT,
        MRZ_ST_L_ROUNDS, MRZ_ST_F_POST, MRZ_ST_F_WAIT, MRZ_ST_F_FOLD, MRZ_ST_F_HELPER,
-       MRZ_ST_H_FIELDS, MRZ_ST_H_FWD, MRZ_ST_H_BWD, MRZ_ST_H_DRAIN, MRZ_ST_H_ROUNDS, MRZ_ST_N };
+       MRZ_ST_H_FIELDS, MRZ_ST_H_FWD, MRZ_ST_H_BWD, MRZ_ST_H_DRAIN, MRZ_ST_H_ROUNDS, MRZ_ST_S_TAB, MRZ_ST_S_PAIR,
+       MRZ_ST_S_INS, MRZ_ST_N };
 
 struct mrz_seq_args {
     const uint8_t *buf;
@@ -506,24 +509,30 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
         const int cfg = (int)s_job[4];
         const int nsx = cfg & 0xff, G = (cfg >> 8) & 0xff;
         const bool want_rev = (cfg >> 16) & 1;
-        const int e = G ? me / G : nsx, s = G ? me % G : 0;
+        int e = G ? me / G : nsx, s = G ? me % G : 0;
+        const bool bwd_job = want_rev && e >= nsx && me - nsx * G < nsx;  // the helpers after the forward ones
+        if (bwd_job) e = me - nsx * G;
         const int64_t op = e < nsx ? (int64_t)s_job[8 + (e & (MRZ_FARM_ENTRIES - 1))] : p0;
         __syncthreads();
         if (tag == ~0ull) return;
         seen = tag;
         if (e >= nsx || op >= p0) continue;
+        if (bwd_job) {
+            // backward half of single_match_len for entry e (one wave: the room is p0 - last_match, mostly small)
+            if (wave == 0) {
+                int64_t maxb = p0 - floor_p;
+                if (op < maxb) maxb = op;
+                const int64_t rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
+                if (lane == 0) mrz_g_storeu(&g->rev[e], (tag << MRZ_FARM_SHIFT) | (unsigned long long)rev);
+            }
+            continue;
+        }
 #ifdef MRZ_SEQ_PROFILE
         const long long h_t0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
         const int64_t off0 = base + (int64_t)s * MRZ_FARM_SPW + (int64_t)wave * MRZ_FARM_WAVE_BYTES;
         const int64_t r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf, off0, lane);
         if (lane == 0) s_res[wave] = r;
-        if (wave == MRZ_SEQ_WAVES - 1 && s == 0 && want_rev) {
-            int64_t maxb = p0 - floor_p;
-            if (op < maxb) maxb = op;
-            const int64_t rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
-            if (lane == 0) mrz_g_storeu(&g->rev[e], (tag << MRZ_FARM_SHIFT) | (unsigned long long)rev);
-        }
         __syncthreads();
         if (threadIdx.x == 0) {
             int64_t best = -1;
@@ -753,7 +762,7 @@ __device__ static void mrz_cull_one(const mrz_cfg &C, mrz_lead &L, int lane) {
 // Farm rounds for the pending entries of one look-up at p0.  Lane e (< nsx <= 16) passes its entry in my_op /
 // my_pending.  Rounds continue from offset `base` until every pending entry has hit its first difference (or maxf);
 // on return lane e holds the forward stop offset (from p0) in *my_fwd and, with want_rev, the backward length in
-// *my_rev.  Needs *C.gnw >= nsx helpers.
+// *my_rev.  Needs *C.gnw >= nsx helpers (2 * nsx with want_rev).
 __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, int64_t maxf, int64_t floor_p,
                                 int64_t base, int nsx, int64_t my_op, bool my_pending, bool want_rev, int lane,
                                 int64_t *stat, int64_t *my_fwd, int64_t *my_rev) {
@@ -765,7 +774,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
     int64_t fwd = 0, rev = 0;
     while (pending) {
         const int nw = *C.gnw;
-        int G = nw / nsx;
+        int G = (want_rev ? nw - nsx : nw) / nsx;  // with want_rev the nsx helpers after the forward ones go backward
         if (G > MRZ_FARM_GMAX) G = MRZ_FARM_GMAX;
         const int nass = nsx * G;
         *C.gseq += 1;
@@ -879,7 +888,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
 #if MRZ_HELPER_WGS > 0
     if (nlong && C.gmb && nsx <= MRZ_FARM_ENTRIES) {
         mrz_farm_census(C);
-        if (*C.gnw >= nsx && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
+        if (*C.gnw >= 2 * nsx && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
             int64_t fw, rv;
             if (!mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
                           &rv))
@@ -964,6 +973,7 @@ __device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_batc
     const int64_t p = L.p, end = C.end, slot_mask = C.slot_mask, max_chain = C.max_chain;
     // ---- one pass over the chain: find_best_match (:426-462) and, when this
     // position is inserted (:579), the probe walk of insert_hash ----------
+    PROF_T0();
     const bool do_insert = (t & L.tag_mask) == L.tag_mask;
     const int64_t better = (L.min_mask << 1) | 1;
     const int my_rank = mrz_ones_rank(t);
@@ -984,6 +994,7 @@ __device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_batc
             const bool empty = (e.off | e.t) == 0;
             const mrz_u64 m_empty = __ballot(empty);
             const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : MRZ_WAVE;
+            PROF_ADD(MRZ_ST_S_TAB);
             if (!ins_found)
                 ins_found = mrz_insert_step(e, empty, t, my_rank, h0 + b, slot_mask, better, max_chain, &round,
                                             &victim_h, &L.count, &L.victim_round, &ins_slot, &ins_kind, &occ_t,
@@ -1008,18 +1019,21 @@ __device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_batc
                     B->pair_res[0][lane] = lng ? -1 : (int)((ml << 8) | rv);
                 }
                 MRZ_WAVE_SYNC();
+                PROF_ADD(MRZ_ST_S_PAIR);
                 int xh = 0, xm = 0;
                 if (!mrz_resolve_entries(C, L, B, mb, mb_seq, p, npass, 0, lane, stat, &mlen, &m_off, &m_rev, &xh, &xm))
                     return false;
                 L.tag_hits += xh;
                 L.tag_misses += xm;
                 todo = rest;
+                PROF_T0R();
             }
             if (first_empty < MRZ_WAVE) break;
         }
     }
 
     // ---- insert + cull (:579-584) -------------------------------------
+    PROF_T0R();
     if (do_insert) {
         int np = 0;
         int64_t it = t, io = p;
@@ -1062,7 +1076,9 @@ __device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_batc
         }
         if (L.count > C.limit) mrz_cull_one(C, L, lane);
     }
-    return mrz_select_emit(C, L, mlen, m_off, m_rev, lane);
+    const bool okk = mrz_select_emit(C, L, mlen, m_off, m_rev, lane);
+    PROF_ADD(MRZ_ST_S_INS);
+    return okk;
 }
 
 // ---- the batch engine -------------------------------------------------------------
