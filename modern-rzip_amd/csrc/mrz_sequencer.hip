@@ -422,8 +422,9 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 // CU keeps only ~8 KiB of loads in flight (~20 GB/s on cold data), so the compares are spread
 // over the whole chip: the grid carries helper workgroups (one per CU: 512 threads x 256 VGPRs
 // fill a CU) that wait on a mailbox in device memory.  A round compares, for every pending
-// entry e, G consecutive 16 KiB stripes: helper w = e*G + s takes stripe s of entry e (2 KiB
-// per wave) and reports where the compare stops inside its stripe, or "equal throughout".
+// entry e, G consecutive 16 KiB stripes: helper ticket w takes stripe w >> 4 of entry w & 15
+// (2 KiB per wave) and reports where the compare stops inside its stripe, or "equal
+// throughout"; the row of helpers after the forward rows measures the backward halves.
 //
 // Hand-off protocol.  Every mailbox word carries the round number in its top 24 bits and the
 // payload (an offset < 2^40) in the low 40, is written with ONE agent-scope (sc1) atomic store
@@ -470,17 +471,24 @@ __device__ __forceinline__ void mrz_g_storeu(unsigned long long *p, unsigned lon
 
 #if MRZ_HELPER_WGS > 0
 __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailbox *g) {
-    __shared__ unsigned long long s_job[26];
-    __shared__ long long s_res[MRZ_SEQ_WAVES];
+    __shared__ unsigned long long s_job[2][26];  // double-buffered by round parity: no barrier after reading it
+    __shared__ unsigned long long s_min;         // lowest stop offset over the waves of this round
+    __shared__ unsigned s_cnt;                   // waves that have contributed
     const int lane = threadIdx.x & 63;
     const int wave = mrz_uni((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0)
-        s_job[25] = __hip_atomic_fetch_add(&g->ready, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        s_job[0][25] = __hip_atomic_fetch_add(&g->ready, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_min = MRZ_FARM_NONE;
+        s_cnt = 0;
+    }
     __syncthreads();
-    const int me = (int)s_job[25];  // my ticket
-    unsigned long long seen = 0;
+    const int me = (int)s_job[0][25];  // my ticket
     if (me >= MRZ_HELPER_WGS) return;
+    const int e = me & (MRZ_FARM_ENTRIES - 1), s = me >> 4;  // entry column, stripe row
+    unsigned long long seen = 0;
+    int par = 0;
     while (true) {
+        par ^= 1;
         if (wave == 0) {
             long long spins = 0;
             while (true) {
@@ -495,31 +503,28 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
                 const bool fresh = tag0 != seen && __ballot(lane < 8 + MRZ_FARM_ENTRIES && tag != tag0) == 0;
                 const bool giveup = quit || spins++ >= MRZ_HELPER_SPIN_LIMIT;
                 if (fresh || giveup) {
-                    if (lane < 8 + MRZ_FARM_ENTRIES) s_job[lane] = w & MRZ_FARM_PAYLOAD;
-                    if (lane == 8 + MRZ_FARM_ENTRIES) s_job[lane] = giveup ? ~0ull : tag0;
+                    if (lane < 8 + MRZ_FARM_ENTRIES) s_job[par][lane] = w & MRZ_FARM_PAYLOAD;
+                    if (lane == 8 + MRZ_FARM_ENTRIES) s_job[par][lane] = giveup ? ~0ull : tag0;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
         __syncthreads();
-        const unsigned long long tag = s_job[8 + MRZ_FARM_ENTRIES];
-        const int64_t p0 = (int64_t)s_job[0], maxf = (int64_t)s_job[1], floor_p = (int64_t)s_job[2];
-        const int64_t base = (int64_t)s_job[3];
-        const int cfg = (int)s_job[4];
-        const int nsx = cfg & 0xff, G = (cfg >> 8) & 0xff;
-        const bool want_rev = (cfg >> 16) & 1;
-        int e = G ? me / G : nsx, s = G ? me % G : 0;
-        const bool bwd_job = want_rev && e >= nsx && me - nsx * G < nsx;  // the helpers after the forward ones
-        if (bwd_job) e = me - nsx * G;
-        const int64_t op = e < nsx ? (int64_t)s_job[8 + (e & (MRZ_FARM_ENTRIES - 1))] : p0;
-        __syncthreads();
+        const unsigned long long tag = s_job[par][8 + MRZ_FARM_ENTRIES];
         if (tag == ~0ull) return;
         seen = tag;
-        if (e >= nsx || op >= p0) continue;
+        const int cfg = (int)s_job[par][4];
+        const int nsx = cfg & 0xff, G = (cfg >> 8) & 0xff;
+        const bool want_rev = (cfg >> 16) & 1;
+        const bool bwd_job = want_rev && s == G;  // the row after the forward rows goes backward
+        if (e >= nsx || (s >= G && !bwd_job)) continue;
+        const int64_t p0 = (int64_t)s_job[par][0], op = (int64_t)s_job[par][8 + e];
+        if (op >= p0) continue;
         if (bwd_job) {
             // backward half of single_match_len for entry e (one wave: the room is p0 - last_match, mostly small)
             if (wave == 0) {
+                const int64_t floor_p = (int64_t)s_job[par][2];
                 int64_t maxb = p0 - floor_p;
                 if (op < maxb) maxb = op;
                 const int64_t rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
@@ -527,20 +532,17 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
             }
             continue;
         }
-#ifdef MRZ_SEQ_PROFILE
-        const long long h_t0 = (long long)__builtin_amdgcn_s_memtime();
-#endif
+        const int64_t maxf = (int64_t)s_job[par][1], base = (int64_t)s_job[par][3];
         const int64_t off0 = base + (int64_t)s * MRZ_FARM_SPW + (int64_t)wave * MRZ_FARM_WAVE_BYTES;
         const int64_t r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf, off0, lane);
-        if (lane == 0) s_res[wave] = r;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t best = -1;
-            for (int w = 0; w < MRZ_SEQ_WAVES && best < 0; w++) best = s_res[w];
-            mrz_g_storeu(&g->res[me], (tag << MRZ_FARM_SHIFT) | (best < 0 ? MRZ_FARM_NONE : (unsigned long long)best));
-#ifdef MRZ_SEQ_PROFILE
-            if (s == 0) g->dbg[1][e] = (long long)__builtin_amdgcn_s_memtime() - h_t0;
-#endif
+        // the last wave to arrive publishes the workgroup's answer (no barrier)
+        if (lane == 0) {
+            if (r >= 0) atomicMin(&s_min, (unsigned long long)r);
+            if (atomicAdd(&s_cnt, 1u) == MRZ_SEQ_WAVES - 1) {
+                const unsigned long long best = atomicExch(&s_min, MRZ_FARM_NONE);
+                s_cnt = 0;
+                mrz_g_storeu(&g->res[me], (tag << MRZ_FARM_SHIFT) | best);
+            }
         }
     }
 }
@@ -762,7 +764,7 @@ __device__ static void mrz_cull_one(const mrz_cfg &C, mrz_lead &L, int lane) {
 // Farm rounds for the pending entries of one look-up at p0.  Lane e (< nsx <= 16) passes its entry in my_op /
 // my_pending.  Rounds continue from offset `base` until every pending entry has hit its first difference (or maxf);
 // on return lane e holds the forward stop offset (from p0) in *my_fwd and, with want_rev, the backward length in
-// *my_rev.  Needs *C.gnw >= nsx helpers (2 * nsx with want_rev).
+// *my_rev.  Needs at least one full row of 16 helper tickets (two with want_rev).
 __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, int64_t maxf, int64_t floor_p,
                                 int64_t base, int nsx, int64_t my_op, bool my_pending, bool want_rev, int lane,
                                 int64_t *stat, int64_t *my_fwd, int64_t *my_rev) {
@@ -773,10 +775,10 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
     mrz_u64 pending = __ballot(my_pending && lane < nsx);
     int64_t fwd = 0, rev = 0;
     while (pending) {
-        const int nw = *C.gnw;
-        int G = (want_rev ? nw - nsx : nw) / nsx;  // with want_rev the nsx helpers after the forward ones go backward
+        // helper ticket w works on entry w & 15, stripe row w >> 4; rows 0..G-1 go forward, row G backward
+        int G = (*C.gnw >> 4) - (want_rev ? 1 : 0);
         if (G > MRZ_FARM_GMAX) G = MRZ_FARM_GMAX;
-        const int nass = nsx * G;
+        const int nass = G << 4;
         *C.gseq += 1;
         const unsigned long long seq = *C.gseq;
         // post: one store instruction carries the whole job
@@ -799,8 +801,8 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int w = lane + 64 * j;
-            ent[j] = w / G;
-            watch[j] = w < nass && ((pending >> (ent[j] & 63)) & 1);
+            ent[j] = w & (MRZ_FARM_ENTRIES - 1);
+            watch[j] = w < nass && ent[j] < nsx && ((pending >> ent[j]) & 1);
         }
         const bool watch_rev = want_rev && lane < nsx && ((pending >> lane) & 1);
         unsigned long long val[4] = { 0, 0, 0, 0 }, rv = 0, ready = 0;
@@ -888,7 +890,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
 #if MRZ_HELPER_WGS > 0
     if (nlong && C.gmb && nsx <= MRZ_FARM_ENTRIES) {
         mrz_farm_census(C);
-        if (*C.gnw >= 2 * nsx && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
+        if (*C.gnw >= 2 * MRZ_FARM_ENTRIES && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
             int64_t fw, rv;
             if (!mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
                           &rv))
@@ -909,7 +911,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
             int64_t rv = 0, cont = 0;
             int64_t ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat,
 #if MRZ_HELPER_WGS > 0
-                                            (C.gmb && *C.gnw >= 1) ? &cont : nullptr
+                                            (C.gmb && *C.gnw >= MRZ_FARM_ENTRIES) ? &cont : nullptr
 #else
                                             nullptr
 #endif
