@@ -33,7 +33,9 @@ enum {
     MRZ_E_NOMEM = -3,    /* device or host allocation failed */
     MRZ_E_HIP = -4,      /* HIP runtime error during a call (see mrz_last_hip_error) */
     MRZ_E_OVERFLOW = -5, /* internal capacity exceeded (should not happen) */
-    MRZ_E_STATE = -6     /* call order violated (e.g. fetch before a chunk ran) */
+    MRZ_E_STATE = -6,    /* call order violated (e.g. fetch before a chunk ran) */
+    MRZ_E_CORRUPT = -7,  /* runzip: invalid record stream / archive (the reference fatal()s "corrupt archive") */
+    MRZ_E_UNSUPPORTED = -8 /* runzip: block type other than CTYPE_NONE (back-end codecs are host code) */
 };
 
 /* where a caller-supplied buffer lives */
@@ -173,6 +175,22 @@ int mrz_blake2b_batch(mrz_ctx *ctx, const void *const *msgs, const int64_t *lens
  * stdout for `n` bytes of stdin: mrz_rs_encoded_size(n) bytes. */
 int64_t mrz_rs_encoded_size(int64_t n);
 int mrz_rs_encode(mrz_ctx *ctx, const void *in, int64_t n, int where, void *out, int out_where, int64_t out_cap);
+
+/* ---- runzip: decoder of the two rzip streams of a chunk ---------- */
+
+/* Replaces the record loop of runzip_chunk (src/runzip.c:277-308) with unzip_literal (:120-157) and
+ * unzip_match (:159-207), given the two (already back-end-decompressed) streams of one chunk:
+ *   s0/s0_len   stream 0: control records, the 00 00 00 terminator and the 4 stored CRC bytes
+ *   s1/s1_len   stream 1: literal bytes
+ * Writes the chunk's bytes to `out` (host or device per out_where) and their count to *out_len;
+ * MRZ_E_ARG with *out_len set when out_cap is too small.  *crc_calc is the CRC-32 of the output
+ * (src/runzip.c:310), *crc_stored the one stored behind the terminator; comparing them is the
+ * caller's business (the reference only does when the archive carries no hash, :311-321).
+ * Invalid records (distance 0 or beyond the history, empty match, truncated stream, literals beyond
+ * stream 1) give MRZ_E_CORRUPT where the reference fatal()s. */
+int mrz_runzip_chunk(mrz_ctx *ctx, const void *s0, int64_t s0_len, const void *s1, int64_t s1_len, int where,
+                     int chunk_bytes, void *out, int out_where, int64_t out_cap, int64_t *out_len, uint32_t *crc_calc,
+                     uint32_t *crc_stored);
 
 #ifdef __cplusplus
 }

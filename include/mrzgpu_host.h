@@ -45,6 +45,13 @@ void mrz_free(void *p);
  * src/stream.c:797-914 for -n): returns max_chunk, *stream_bufsize optional */
 int64_t mrz_plan(const mrz_control *control, int64_t st_size, int64_t *stream_bufsize);
 
+/* `mrzip -d` of a whole -n archive held in memory: runzip_fd (src/runzip.c:332-437) over
+ * runzip_chunk (:226-330), the block chains of the two streams (fill_buffer, src/stream.c:1412-1571;
+ * CTYPE_NONE blocks only -- anything a back-end codec wrote gives MRZ_E_UNSUPPORTED) and the final
+ * hash check (:384-412; per-chunk CRC instead when the archive carries no hash, :311-321).
+ * *out is malloc'd by the library (mrz_free).  Record decoding runs on the GPU (mrz_runzip_chunk). */
+int mrz_runzip_buffer(int device, const void *mrz, int64_t n, void **out, int64_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

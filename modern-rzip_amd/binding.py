@@ -98,6 +98,11 @@ def load_library(path=None):
         lib.mrz_rs_encoded_size.argtypes = [i64]
         lib.mrz_rs_encoded_size.restype = i64
         lib.mrz_rs_encode.argtypes = [vp, vp, i64, ci, vp, ci, i64]
+    if hasattr(lib, "mrz_runzip_chunk"):
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        lib.mrz_runzip_chunk.argtypes = [vp, vp, i64, vp, i64, ci, ci, vp, ci, i64, ctypes.POINTER(i64), u32p, u32p]
+    if hasattr(lib, "mrz_runzip_buffer"):
+        lib.mrz_runzip_buffer.argtypes = [ci, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     if hasattr(lib, "mrz_rzip_buffer"):
         lib.mrz_rzip_buffer.argtypes = [ctypes.POINTER(Control), vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                         ctypes.POINTER(Stats), vp]
@@ -240,6 +245,28 @@ class RzipContext:
         _check(self.lib, self.lib.mrz_rs_encode(self.ctx, ptr, n, where, out, MEM_HOST, total), self.ctx)
         return out.raw
 
+    # ---- runzip (src/runzip.c:120-207,277-308) ----
+    def runzip_chunk(self, s0, s1, chunk_bytes_, out_cap, out=None):
+        """Decodes the two streams of one chunk.  Returns (bytes or None, out_len, crc_calc, crc_stored);
+        with `out` = (device pointer, nbytes) or a cuda tensor the bytes stay on the device."""
+        p0, n0, w0, k0 = _as_ptr(s0)
+        p1, n1, w1, k1 = _as_ptr(s1)
+        if w0 != w1:
+            raise MrzError("runzip_chunk: both streams must live in the same memory space")
+        got = ctypes.c_int64()
+        cc, cs = ctypes.c_uint32(), ctypes.c_uint32()
+        if out is None:
+            buf = ctypes.create_string_buffer(max(1, out_cap))
+            rc = self.lib.mrz_runzip_chunk(self.ctx, p0, n0, p1, n1, w0, chunk_bytes_, buf, MEM_HOST, out_cap,
+                                           ctypes.byref(got), ctypes.byref(cc), ctypes.byref(cs))
+            _check(self.lib, rc, self.ctx)
+            return buf.raw[:got.value], got.value, cc.value, cs.value
+        po, no, wo, ko = _as_ptr(out)
+        rc = self.lib.mrz_runzip_chunk(self.ctx, p0, n0, p1, n1, w0, chunk_bytes_, po, wo, min(no, out_cap),
+                                       ctypes.byref(got), ctypes.byref(cc), ctypes.byref(cs))
+        _check(self.lib, rc, self.ctx)
+        return None, got.value, cc.value, cs.value
+
     # ---- BLAKE2b (common/blake2b.h:47-49) ----
     def blake2b(self, data, outlen=64, pieces=None):
         st = ctypes.c_void_p()
@@ -281,5 +308,20 @@ def rzip_buffer(data, level=7, window=0, unlimited=False, ramsize=60 << 30, devi
                                     ctypes.byref(st), md5))
     try:
         return ctypes.string_at(out, out_len.value), st, md5.raw
+    finally:
+        lib.mrz_free(out)
+
+
+def runzip_buffer(mrz, device=0, lib=None):
+    """`mrzip -d` of a -n archive held in memory (mrz_runzip_buffer).  Returns the original bytes."""
+    lib = lib or load_library()
+    ptr, n, where, keep = _as_ptr(mrz)
+    if where != MEM_HOST:
+        raise MrzError("runzip_buffer takes host memory")
+    out = ctypes.c_void_p()
+    out_len = ctypes.c_int64()
+    _check(lib, lib.mrz_runzip_buffer(device, ptr, n, ctypes.byref(out), ctypes.byref(out_len)))
+    try:
+        return ctypes.string_at(out, out_len.value)
     finally:
         lib.mrz_free(out)

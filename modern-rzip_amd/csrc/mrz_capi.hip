@@ -51,6 +51,8 @@ extern "C" const char *mrz_strerror(int code) {
         case MRZ_E_HIP: return "HIP runtime error";
         case MRZ_E_OVERFLOW: return "internal capacity exceeded";
         case MRZ_E_STATE: return "call order violated";
+        case MRZ_E_CORRUPT: return "corrupt record stream or archive";
+        case MRZ_E_UNSUPPORTED: return "block type not handled on this path (back-end codecs are host code)";
         default: return "unknown error";
     }
 }
@@ -88,6 +90,9 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_crc_parts);
     hipFree(ctx->d_crc_out);
     if (ctx->d_gmailbox) hipFree(ctx->d_gmailbox);
+    if (ctx->rz_scratch) hipFree(ctx->rz_scratch);
+    if (ctx->d_rz_out) hipFree(ctx->d_rz_out);
+    if (ctx->d_rz_done) hipFree(ctx->d_rz_done);
     if (ctx->d_rs_tables) hipFree(ctx->d_rs_tables);
     if (ctx->d_rs_out) hipFree(ctx->d_rs_out);
     if (ctx->lz4_scratch) hipFree(ctx->lz4_scratch);

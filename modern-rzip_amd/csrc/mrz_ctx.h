@@ -47,6 +47,12 @@ struct mrz_ctx {
     void *d_rs_tables;  // Reed-Solomon tables (mrz_rs.hip)
     uint8_t *d_rs_out;
     int64_t rs_out_cap;
+    void *rz_scratch;  // runzip: parse tables, records, staged streams (mrz_runzip.hip)
+    int64_t rz_scratch_cap;
+    uint8_t *d_rz_out;
+    int64_t rz_out_cap;
+    unsigned *d_rz_done;
+    int64_t rz_done_cap;
     int have_chunk;
 
     // LZ4 / BLAKE2b scratch (owned by their translation units, freed in mrz_close)

@@ -352,3 +352,100 @@ extern "C" int mrz_rzip_fd(const mrz_control *ctl, int fd_in, int fd_out, mrz_st
     }
     return MRZ_OK;
 }
+
+// ---- decompress side: `mrzip -d` of a -n archive (runzip_fd, src/runzip.c:332-437) -----------------
+namespace {
+
+int64_t peek_le(const uint8_t *p, int nbytes) {
+    uint64_t v = 0;
+    for (int i = 0; i < nbytes; i++) v |= (uint64_t)p[i] << (8 * i);
+    return (int64_t)v;
+}
+
+// follows one stream's block chain and concatenates the payloads (fill_buffer, src/stream.c:1412-1571);
+// only CTYPE_NONE (3) blocks: the back-end codecs stay host code outside this library
+int gather_stream(const uint8_t *mrz, int64_t n, int64_t initial_pos, int64_t head_at, int cb, std::vector<uint8_t> &dst,
+                  int64_t *end_max) {
+    int64_t at = head_at;
+    for (;;) {
+        if (at + 1 + 3 * cb > n) return MRZ_E_CORRUPT;
+        const int ctype = mrz[at];
+        const int64_t c_len = peek_le(mrz + at + 1, cb), u_len = peek_le(mrz + at + 1 + cb, cb);
+        const int64_t next = peek_le(mrz + at + 1 + 2 * cb, cb);
+        if (ctype != 3) return MRZ_E_UNSUPPORTED;
+        if (c_len != u_len || c_len < 0) return MRZ_E_CORRUPT;
+        const int64_t pay = at + 1 + 3 * cb;
+        if (pay + c_len > n) return MRZ_E_CORRUPT;
+        dst.insert(dst.end(), mrz + pay, mrz + pay + c_len);
+        if (pay + c_len > *end_max) *end_max = pay + c_len;
+        if (!next) return MRZ_OK;
+        if (next < 0 || initial_pos + next <= at) return MRZ_E_CORRUPT;  // chains only run forward
+        at = initial_pos + next;
+    }
+}
+
+}  // namespace
+
+extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void **out, int64_t *out_len) {
+    if (!mrz_v || !out || !out_len) return MRZ_E_ARG;
+    const uint8_t *mrz = (const uint8_t *)mrz_v;
+    if (n < 20 || memcmp(mrz, "MRZI", 4)) return MRZ_E_CORRUPT;  // read_magic, src/mrzip.c:225-321
+    if (mrz[15]) return MRZ_E_UNSUPPORTED;                        // encrypted
+    const int64_t expected = peek_le(mrz + 6, 8);
+    const int hash_code = mrz[14];
+    if (hash_code != 0 && hash_code != 1) return MRZ_E_UNSUPPORTED;  // MD5 (default) or CRC only
+    uint8_t *res = (uint8_t *)malloc((size_t)(expected > 0 ? expected : 1));
+    if (!res) return MRZ_E_NOMEM;
+    mrz_ctx *ctx = nullptr;
+    int rc = mrz_open(&ctx, device, 7, 0);
+    int64_t at = 20 + mrz[19], total = 0;
+    std::vector<uint8_t> s0, s1;
+    while (!rc) {  // runzip_chunk, src/runzip.c:226-330
+        if (at + 2 > n) {
+            rc = MRZ_E_CORRUPT;
+            break;
+        }
+        const int cb = mrz[at], eof = mrz[at + 1];
+        if (cb < 1 || cb > 8 || at + 2 + cb > n) {
+            rc = MRZ_E_CORRUPT;
+            break;
+        }
+        at += 2 + cb;  // chunk_bytes, eof, chunk size
+        const int64_t initial_pos = at;
+        int64_t end_max = initial_pos + 2 * (1 + 3 * cb);
+        s0.clear();
+        s1.clear();
+        rc = gather_stream(mrz, n, initial_pos, initial_pos, cb, s0, &end_max);
+        if (!rc) rc = gather_stream(mrz, n, initial_pos, initial_pos + 1 + 3 * cb, cb, s1, &end_max);
+        if (rc) break;
+        int64_t got = 0;
+        uint32_t crc_calc = 0, crc_stored = 0;
+        rc = mrz_runzip_chunk(ctx, s0.data(), (int64_t)s0.size(), s1.data(), (int64_t)s1.size(), MRZ_MEM_HOST, cb,
+                              res + total, MRZ_MEM_HOST, expected - total, &got, &crc_calc, &crc_stored);
+        if (rc == MRZ_E_ARG) rc = MRZ_E_CORRUPT;  // more output than the header promised
+        if (rc) break;
+        if (!hash_code && crc_calc != crc_stored) {  // "Bad checksum", src/runzip.c:317-320 (only without a hash)
+            rc = MRZ_E_CORRUPT;
+            break;
+        }
+        total += got;
+        at = end_max;
+        if (eof) break;
+    }
+    if (ctx) mrz_close(ctx);
+    if (!rc && total != expected) rc = MRZ_E_CORRUPT;
+    if (!rc && hash_code == 1) {  // src/runzip.c:384-412
+        uint8_t d[16];
+        Md5 h;
+        h.update(res, (size_t)total);
+        h.finish(d);
+        if (at + 16 > n || memcmp(d, mrz + at, 16)) rc = MRZ_E_CORRUPT;
+    }
+    if (rc) {
+        free(res);
+        return rc;
+    }
+    *out = res;
+    *out_len = total;
+    return MRZ_OK;
+}

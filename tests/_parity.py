@@ -20,7 +20,18 @@ def check_chunk(lib, oracle, data, level=7, victim_round=0, table=False):
         assert s0 == want["s0"]
         if table:
             assert ctx.fetch_table() == want["table"]
+        check_runzip(ctx, data, want["s0"], want["s1"])
     return want
+
+
+def check_runzip(ctx, data, s0, s1, chunk_bytes_=None):
+    """mrz_runzip_chunk on the ORACLE's streams gives the input back; computed == stored == zlib CRC."""
+    import zlib
+    cb = chunk_bytes_ or m.chunk_bytes(len(data), lib=ctx.lib)
+    back, n, crc_calc, crc_stored = ctx.runzip_chunk(s0, s1, cb, len(data))
+    assert n == len(data)
+    assert back == data
+    assert crc_calc == crc_stored == (zlib.crc32(data) & 0xFFFFFFFF)
 
 
 def check_file(lib, oracle, data, level=7, **kw):
@@ -32,4 +43,5 @@ def check_file(lib, oracle, data, level=7, **kw):
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
     rc, back = oracle.decompress(got)
     assert rc == 0 and back == data
+    assert m.runzip_buffer(want, lib=lib) == data  # mrzip -d of the ORACLE's archive through the GPU decoder
     return got

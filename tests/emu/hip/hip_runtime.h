@@ -74,6 +74,7 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::shfl(v, em
 template <typename T> static inline T __hip_atomic_load(T *p, int, int) { return *(volatile T *)p; }
 template <typename T> static inline void __hip_atomic_store(T *p, T v, int, int) { *(volatile T *)p = v; }
 template <typename T> static inline T __hip_atomic_fetch_add(T *p, T v, int, int) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline bool __hip_atomic_compare_exchange_strong(T *p, T *expect, T v, int, int, int) { if (*p == *expect) { *p = v; return true; } *expect = *p; return false; }
 static inline void __builtin_amdgcn_s_sleep(int) { emu::yield(); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
@@ -91,6 +92,9 @@ struct emu_event { double t; };
 static inline double emu_now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 2; return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }

@@ -123,3 +123,33 @@ def test_rs_encoder(emu_lib, oracle):
         for n in (0, 1, 222, 223, 224, 100000):
             d = _util.xorshift_noise(n, seed=n + 3)
             assert ctx.rs_encode(d) == oracle.rs_encode(d), n
+
+
+def test_runzip_overlapping_and_corrupt_streams(emu_lib, oracle):
+    # hand-made streams: literal "abc", match len 10 dist 3 (the 3 history bytes repeat, src/runzip.c:182-199),
+    # match len 4 dist 13 (plain copy), terminator + CRC
+    want = b"abc" + b"abcabcabca" + b"abca"
+    crc = zlib.crc32(want) & 0xFFFFFFFF
+    s0 = (bytes([0, 3, 0]) + bytes([1, 10, 0, 3]) + bytes([1, 4, 0, 13]) + bytes([0, 0, 0]) + crc.to_bytes(4, "big"))
+    with m.RzipContext(level=7, max_chunk=64, lib=emu_lib) as ctx:
+        back, n, cc, cs = ctx.runzip_chunk(s0, b"abc", 1, 64)
+        assert back == want and cc == cs == crc
+        # distance beyond the history / zero distance / empty match / literals beyond stream 1 / no terminator
+        for bad in (bytes([0, 3, 0, 1, 4, 0, 4, 0, 0, 0]) + bytes(4),
+                    bytes([0, 3, 0, 1, 4, 0, 0, 0, 0, 0]) + bytes(4),
+                    bytes([0, 3, 0, 1, 0, 0, 1, 0, 0, 0]) + bytes(4),
+                    bytes([0, 9, 0, 0, 0, 0]) + bytes(4),
+                    bytes([0, 3, 0, 1, 4, 0, 3])):
+            with pytest.raises(m.MrzError):
+                ctx.runzip_chunk(bad, b"abc", 1, 64)
+
+
+def test_runzip_many_tiles(emu_lib, oracle):
+    # output of several 32 KiB decode tiles, stream 0 of several 1 KiB parse tiles, matches reaching back across tiles
+    words = [_util.xorshift_noise(48, seed=100 + i) for i in range(40)]
+    order = _util.xorshift_noise(3000, seed=7)
+    data = _util.rep64k(5, seed=3, period=40000) + b"".join(words[b % 40] + bytes([b]) for b in order)
+    want = oracle.rzip_chunk(data, level=7)
+    assert len(want["s0"]) > 3000
+    with m.RzipContext(level=7, max_chunk=len(data), lib=emu_lib) as ctx:
+        _parity.check_runzip(ctx, data, want["s0"], want["s1"])
