@@ -17,7 +17,7 @@
 //      counts in front of it;
 //   3. parse, for real: one thread per tile writes its records {out_pos, literal offset or
 //      distance} and validates them;
-//   4. decode: the output is cut into 32 KiB tiles claimed in order by persistent workgroups.
+//   4. decode: the output is cut into tiles (8-128 KiB, by record density) claimed in order by persistent workgroups.
 //      A match needs its history: bytes of earlier tiles are awaited through per-tile done
 //      flags (release / acquire at agent scope -- tiles are written on different XCDs), bytes
 //      of the same tile are ordered by workgroup barriers.  A workgroup only ever waits for
@@ -36,7 +36,11 @@
 #define MRZ_UZ_PHMAX 11       // entry offsets: record size <= 3 + 8
 #define MRZ_UZ_END 255        // parse state: terminator seen
 #define MRZ_UZ_ERR 254        // parse state: record runs past the end of stream 0
-#define MRZ_UZ_TO 32768       // output tile of the decode pass
+#define MRZ_UZ_TSHIFT_MIN 13  // output tile of the decode pass: 8 KiB (many short records) .. 128 KiB (few long ones)
+#define MRZ_UZ_TSHIFT_MAX 17
+#ifndef MRZ_UZ_DEC_THREADS
+#define MRZ_UZ_DEC_THREADS 512
+#endif
 #define MRZ_UZ_THREADS 256
 #define MRZ_UZ_SCAN_THREADS 128  // run tables of the scan live in LDS: 128 x 12 x 25 B
 #define MRZ_UZ_MATCH (1ull << 63)
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_parse2_kernel(const uin
 
 // workgroup-wide copy of n bytes (both sides arbitrarily aligned): 16 B per thread and step
 __device__ __forceinline__ void mrz_uz_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n) {
-    for (int64_t o = (int64_t)threadIdx.x * 16; o < n; o += (int64_t)MRZ_UZ_THREADS * 16) {
+    for (int64_t o = (int64_t)threadIdx.x * 16; o < n; o += (int64_t)MRZ_UZ_DEC_THREADS * 16) {
         if (o + 16 <= n) {
             const uint4 v = mrz_ld16(src + o);
             __builtin_memcpy(dst + o, &v, 16);
@@ -254,11 +258,13 @@ __device__ __forceinline__ void mrz_uz_release() {
 #endif
 }
 
-__global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_decode_kernel(const mrz_urec *__restrict__ rec, int64_t nrec,
+__global__ __launch_bounds__(MRZ_UZ_DEC_THREADS) void mrz_uz_decode_kernel(const mrz_urec *__restrict__ rec, int64_t nrec,
                                                                        const uint8_t *__restrict__ s1,
                                                                        uint8_t *__restrict__ out, int64_t out_total,
-                                                                       int64_t ntiles, unsigned *__restrict__ done,
+                                                                       int64_t ntiles, int tshift,
+                                                                       unsigned *__restrict__ done,
                                                                        mrz_uz_hdr *__restrict__ hdr) {
+    const int64_t TO = (int64_t)1 << tshift;
     __shared__ long long s_tile, s_first, s_prefix;
     __shared__ int s_fail;
     long long known = 0;  // every tile below this index is known to be complete
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_decode_kernel(const mrz
             s_fail = 0;
             if (t < ntiles) {
                 // last record that starts at or before the tile's first byte
-                const int64_t T0 = t * MRZ_UZ_TO;
+                const int64_t T0 = (t << tshift);
                 int64_t lo = 0, hi = nrec - 1;
                 while (lo < hi) {
                     const int64_t mid = (lo + hi + 1) >> 1;
@@ -285,8 +291,8 @@ __global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_decode_kernel(const mrz
         __syncthreads();
         const long long t = s_tile;
         if (t >= ntiles) return;
-        const int64_t T0 = t * MRZ_UZ_TO;
-        const int64_t T1 = T0 + MRZ_UZ_TO < out_total ? T0 + MRZ_UZ_TO : out_total;
+        const int64_t T0 = (t << tshift);
+        const int64_t T1 = T0 + TO < out_total ? T0 + TO : out_total;
         int64_t written_to = T0;  // bytes of this tile below this are written (maybe not yet ordered)
         bool unordered = false;   // stores since the last barrier
         for (int64_t r = s_first; r < nrec; r++) {
@@ -305,15 +311,17 @@ __global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_decode_kernel(const mrz
                 const int64_t h0 = span == len ? from + (x0 - o) : from;
                 const int64_t h1 = span == len ? from + (x1 - o) : from + span;
                 if (h0 < T0) {
-                    const long long need_hi = (long long)(((h1 < T0 ? h1 : T0) - 1) / MRZ_UZ_TO);
+                    const long long need_hi = (long long)(((h1 < T0 ? h1 : T0) - 1) >> tshift);
                     if (need_hi >= known) {
                         if (threadIdx.x == 0) {
                             long long spins = 0;
-                            long long p = (long long)__hip_atomic_load(&hdr->prefix_done, __ATOMIC_ACQUIRE,
+                            // relaxed polls (an acquire load would invalidate the L2 on every iteration); one acquire
+                            // fence by every thread follows the barrier below
+                            long long p = (long long)__hip_atomic_load(&hdr->prefix_done, __ATOMIC_RELAXED,
                                                                        __HIP_MEMORY_SCOPE_AGENT);
-                            for (long long q = (long long)(h0 / MRZ_UZ_TO) > p ? (long long)(h0 / MRZ_UZ_TO) : p;
+                            for (long long q = (long long)(h0 >> tshift) > p ? (long long)(h0 >> tshift) : p;
                                  q <= need_hi; q++) {
-                                while (!__hip_atomic_load(&done[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+                                while (!__hip_atomic_load(&done[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                                     if (spins++ > MRZ_UZ_SPIN_LIMIT) {
                                         s_fail = 1;
                                         break;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_decode_kernel(const mrz
                 if (span == len)
                     mrz_uz_copy(out + x0, out + from + (x0 - o), x1 - x0);
                 else  // the first `dist` history bytes repeat (src/runzip.c:182-199)
-                    for (int64_t x = x0 + threadIdx.x; x < x1; x += MRZ_UZ_THREADS) out[x] = out[from + (x - o) % span];
+                    for (int64_t x = x0 + threadIdx.x; x < x1; x += MRZ_UZ_DEC_THREADS) out[x] = out[from + (x - o) % span];
             }
             written_to = x1;
             unordered = true;
@@ -351,12 +359,12 @@ __global__ __launch_bounds__(MRZ_UZ_THREADS) void mrz_uz_decode_kernel(const mrz
         __syncthreads();
         if (threadIdx.x == 0) {
             mrz_uz_release();
-            __hip_atomic_store(&done[t], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&done[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // after the release fence
             // push the completed prefix forward as far as the flags allow
             unsigned long long p = __hip_atomic_load(&hdr->prefix_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((long long)p < ntiles && __hip_atomic_load(&done[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+            while ((long long)p < ntiles && __hip_atomic_load(&done[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 unsigned long long expect = p;
-                if (__hip_atomic_compare_exchange_strong(&hdr->prefix_done, &expect, p + 1, __ATOMIC_RELEASE,
+                if (__hip_atomic_compare_exchange_strong(&hdr->prefix_done, &expect, p + 1, __ATOMIC_RELAXED,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                     p = p + 1;
                 else
@@ -431,17 +439,23 @@ extern "C" int mrz_runzip_chunk(mrz_ctx *ctx, const void *s0, int64_t s0_len, co
         if (rc) return rc;
         d_out = ctx->d_rz_out;
     }
-    const int64_t otiles = (h.out_total + MRZ_UZ_TO - 1) / MRZ_UZ_TO;
+    // tile size from the record density: about 32 records per tile, 8 KiB .. 128 KiB
+    int tshift = MRZ_UZ_TSHIFT_MIN;
+    {
+        const int64_t target = h.out_total / (h.nrec > 0 ? h.nrec : 1) * 32;
+        while (tshift < MRZ_UZ_TSHIFT_MAX && ((int64_t)1 << tshift) < target) tshift++;
+    }
+    const int64_t otiles = (h.out_total + ((int64_t)1 << tshift) - 1) >> tshift;
     if (otiles) {
         rc = mrz_grow(ctx, &ctx->d_rz_done, &ctx->rz_done_cap, otiles);
         if (rc) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_rz_done, 0, (size_t)otiles * sizeof(unsigned), s));
         int cus = 0;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        int64_t grid = (int64_t)(cus > 0 ? cus : 64) * 4;
+        int64_t grid = (int64_t)(cus > 0 ? cus : 64) * 2;
         if (grid > otiles) grid = otiles;
-        hipLaunchKernelGGL(mrz_uz_decode_kernel, dim3((unsigned)grid), dim3(MRZ_UZ_THREADS), 0, s, d_rec, h.nrec + 1,
-                           d_s1, d_out, h.out_total, otiles, ctx->d_rz_done, d_hdr);
+        hipLaunchKernelGGL(mrz_uz_decode_kernel, dim3((unsigned)grid), dim3(MRZ_UZ_DEC_THREADS), 0, s, d_rec, h.nrec + 1,
+                           d_s1, d_out, h.out_total, otiles, tshift, ctx->d_rz_done, d_hdr);
         HIPCHK(ctx, hipGetLastError());
     }
     // CRC-32 of the output (gcry_md_read at src/runzip.c:310) and the stored one behind the terminator
