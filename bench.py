@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--level", type=int, default=7)
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed GPU decode of the result")
     args = ap.parse_args()
 
     import torch
@@ -129,6 +130,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # untimed self-check on every rank: the streams of the last step decode back to the input (GPU runzip)
+    verify = None
+    if not args.no_verify and res is not None:
+        back = torch.empty(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        v0 = time.perf_counter()
+        _, got, crc_calc, crc_stored = ctx.runzip_chunk((res.d_s0, res.s0_len), (res.d_s1, res.s1_len),
+                                                        m.chunk_bytes(n, lib=lib), n, out=back)
+        vdt = time.perf_counter() - v0
+        same = got == n and crc_calc == crc_stored == res.crc32 and bool(torch.equal(back, data))
+        if not same:
+            raise SystemExit(f"rank {rank}: decode of the benchmark result does not reproduce the input")
+        verify = {"decoded_equals_input": True, "decode_GBps": round(n / vdt / 1e9, 2)}
+        del back
+
     if rank == 0:
         steps = args.steps
         total_in = n * steps * world
@@ -161,6 +177,8 @@ def main():
             "result": {"s0_len": res.s0_len, "s1_len": res.s1_len, "matches": res.stats.matches,
                        "inserts": res.stats.inserts, "crc32": f"{res.crc32:08x}"},
         }
+        if verify:
+            out["verify"] = verify
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(int(min(args.cpu_sample_gib, args.gib) * GIB))
         print(json.dumps(out), flush=True)

@@ -156,6 +156,23 @@ def test_runzip_device_roundtrip_1gib(gpu_lib):
     assert torch.equal(out, t)
 
 
+def test_bench_config_roundtrip_10gib(gpu_lib):
+    """BASELINE configs[1] at full size (10 GiB, chunk_bytes 5): encode and decode in HBM, outputs must agree
+    with the input, the CRCs with each other, and the stream accounting must add up."""
+    import torch
+    t = w.rep64k_device(163840, "cuda")
+    n = t.numel()
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    with m.RzipContext(lib=gpu_lib, max_chunk=n) as ctx:
+        res, _, _ = ctx.rzip_chunk(t, fetch=False)
+        assert m.chunk_bytes(n, lib=gpu_lib) == 5
+        _, got, cc, cs = ctx.runzip_chunk((res.d_s0, res.s0_len), (res.d_s1, res.s1_len), 5, n, out=out)
+        assert ctx.crc32(t) == res.crc32
+    assert got == n and cc == cs == res.crc32
+    assert res.stats.literal_bytes + res.stats.match_bytes == n and res.stats.literal_bytes == res.s1_len
+    assert torch.equal(out, t)
+
+
 @pytest.mark.parametrize("kind", ["text", "noise", "tar"])
 def test_runzip_roundtrip_shapes(gpu_lib, kind):
     """GPU encoder -> GPU decoder on non-periodic shapes (many short records / no matches / mixed)."""
