@@ -78,7 +78,16 @@
 #define PROF_ADD(k)
 #endif
 
-// diagnostics kept in mrz_seq_state.prof (always on, a handful of scalar adds)
+// diagnostics kept in mrz_seq_state.prof: counted only in -DMRZ_SEQ_STATS / -DMRZ_SEQ_PROFILE builds (the array is
+// indexed dynamically, so it lives in scratch memory: not something to pay for in the product build)
+#if defined(MRZ_SEQ_PROFILE) && !defined(MRZ_SEQ_STATS)
+#define MRZ_SEQ_STATS 1
+#endif
+#ifdef MRZ_SEQ_STATS
+#define ST_ADD(k, v) (stat[k] += (v))
+#else
+#define ST_ADD(k, v) ((void)0)
+#endif
 enum { MRZ_ST_BATCHES, MRZ_ST_BATCH_LANES, MRZ_ST_SEQ, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT,
        MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS, MRZ_ST_CUT_CASCADE, MRZ_ST_PAIRS, MRZ_ST_BATCH_FORMED,
        MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_WALK2, MRZ_ST_T_PAIRS, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_COMMIT,
@@ -253,7 +262,9 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mr
                 for (int w = 1; w < MRZ_STRIPE_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
             }
             LPROF(MRZ_ST_L_WAIT);
+#ifdef MRZ_SEQ_STATS
             if (stat) stat[MRZ_ST_L_ROUNDS] += 1;
+#endif
             if (best >= 0) {
                 fwd = best;
                 break;
@@ -678,6 +689,7 @@ struct mrz_lead {  // wave-uniform; what hash_search keeps in locals / rzip_stat
     int64_t p, cur_p, cur_ofs, cur_len, last_match;
     int64_t min_mask, tag_mask, count, clean_ptr, victim_round;
     int64_t n_events, inserts, tag_hits, tag_misses;
+    int64_t last_len;  // length of the last emitted match (scheduling hint only)
 };
 
 struct mrz_cfg {
@@ -691,6 +703,7 @@ struct mrz_cfg {
     int *gnw;                  // helper tickets the leader has seen so far
     int n_helpers;             // helper workgroups in this launch
     int64_t *farm_hint;        // forward length of the last long match: go to the farm at once when it was big
+    int *long_seen;            // set when a look-up had entries beyond the 64-byte reach (scheduling hint only)
 };
 
 // lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
@@ -715,6 +728,7 @@ __device__ __forceinline__ bool mrz_select_emit(const mrz_cfg &C, mrz_lead &L, i
             C.events[L.n_events] = ev;
         }
         L.n_events++;
+        L.last_len = L.cur_len;
         L.last_match = L.cur_p + L.cur_len;
         L.cur_p = L.p = L.last_match;
         L.cur_len = 0;
@@ -831,7 +845,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
             if (seen > *C.gnw) *C.gnw = seen;
         }
         PROF_ADD(MRZ_ST_F_WAIT);
-        stat[MRZ_ST_FARMED] += 1;
+        ST_ADD(MRZ_ST_FARMED, 1);
         // fold: the stop of entry e is the lowest offset any of its stripes reported
         if (lane < MRZ_FARM_ENTRIES) B->farm_min[lane] = MRZ_FARM_NONE;
         MRZ_WAVE_SYNC();
@@ -885,6 +899,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
     }
     const mrz_u64 longmask = __ballot(lane < nsx && my_r < 0);
     const int nlong = __popcll(longmask);
+    if (nlong) *C.long_seen = 1;
     const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
     bool farmed = false;
 #if MRZ_HELPER_WGS > 0
@@ -1314,7 +1329,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
                 } else
                     misses++;
             }
-            stat[MRZ_ST_PAIRS] += npairs;
+            ST_ADD(MRZ_ST_PAIRS, npairs);
         }
     }
 
@@ -1435,16 +1450,16 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     const mrz_u64 m_long = __ballot(have && act && !cplx && needs_long);
     const mrz_u64 m_stop_any = m_cplx | m_long;
     int n_ok = m_stop_any ? __ffsll((long long)m_stop_any) - 1 : __popcll(m_have);
-    stat[MRZ_ST_BATCH_FORMED] += __popcll(m_have);
+    ST_ADD(MRZ_ST_BATCH_FORMED, __popcll(m_have));
     if (m_stop_any && ((m_cplx >> n_ok) & 1)) {
         const int reason = mrz_lane_read(why, n_ok);
-        if (reason > 0 && reason < MRZ_ST_N) stat[reason] += 1;
+        if (reason > 0 && reason < MRZ_ST_N) ST_ADD(reason, 1);
     } else if (m_stop_any) {
         // The cut lane is sound except that some of its tag-equal entries run past the per-lane
         // reach: extend those with the whole workgroup (striped long path), fold the lane's
         // entries in probe order, and keep the lane as the last one of this batch.
         const int x = n_ok;
-        stat[MRZ_ST_CUT_LONG] += 1;
+        ST_ADD(MRZ_ST_CUT_LONG, 1);
         const int nsx = mrz_lane_read(nsame < MRZ_SMAX ? nsame : MRZ_SMAX, x);
         const int64_t qx = mrz_bcast64(q, x);
         int64_t xb = 0, xoff = 0, xrev = 0;
@@ -1505,11 +1520,11 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     }
     if (emit_lane >= 0) {
         n_ok = emit_lane + 1;
-        stat[MRZ_ST_BATCH_EMITS] += 1;
+        ST_ADD(MRZ_ST_BATCH_EMITS, 1);
     }
     PROF_ADD(MRZ_ST_T_FOLD);
-    stat[MRZ_ST_BATCHES] += 1;
-    stat[MRZ_ST_BATCH_LANES] += n_ok;
+    ST_ADD(MRZ_ST_BATCHES, 1);
+    ST_ADD(MRZ_ST_BATCH_LANES, n_ok);
     const mrz_u64 keep = mrz_low_mask(n_ok);
     const bool mine = have && ((keep >> lane) & 1);
 
@@ -1627,6 +1642,8 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     C.n_helpers = a.n_helpers;
     int64_t farm_hint = 0;
     C.farm_hint = &farm_hint;
+    int long_seen = 0;
+    C.long_seen = &long_seen;
     mrz_lead L;
     L.p = st->p;
     L.cur_p = st->cur_p;
@@ -1642,6 +1659,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     L.inserts = st->inserts;
     L.tag_hits = st->tag_hits;
     L.tag_misses = st->tag_misses;
+    L.last_len = 0;
 
     const int64_t seg_start = a.seg_start;
     const int64_t seg_end = a.seg_start + a.seg_len;
@@ -1656,9 +1674,19 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     int width = 64;            // batch width, adapted to how many lanes recent batches could commit
     int low_yield = 0;         // consecutive batches that committed <= 2 candidates
     int seq_credit = 0;        // candidates to run through the cooperative path before batching again
-    bool prefer_seq = false;   // right after an emission the next candidate is usually a long match
+    // Right after an emission the next candidate often has long matches again (repetitive input): a batch
+    // would be formed, walked and probed only to be cut at its first lane.  Two saturating counters, one per
+    // class of the emitted match (short / >= GREAT_MATCH), learn whether that is so; when it is, the first
+    // candidate after an emission goes straight through the cooperative path.
+    bool after_emit = false;
+    int emit_cls = 0;
+    int pred_long[2] = { 0, 0 };
+#ifdef MRZ_SEQ_STATS
     int64_t stat[MRZ_ST_N];
     for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
+#else
+    int64_t *stat = nullptr;
+#endif
 
     int sc_seq = 0;
     int64_t sc_last = -1;
@@ -1704,10 +1732,13 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         PROF_ADD(MRZ_ST_T_WINDOW);
         int used = 0;
         const int64_t ev_before = L.n_events;
+        const bool first_after_emit = after_emit;
+        const bool go_seq = first_after_emit && pred_long[emit_cls] >= 2;
+        long_seen = 0;
 #ifndef MRZ_NO_BATCH
         if (seq_credit > 0)
             seq_credit--;  // a stretch where every candidate has long matches: one at a time is cheaper
-        else if (!prefer_seq) {
+        else if (!go_seq) {
             used = mrz_batch_step(C, L, &batch, a.tags, seg_start, wb, w, epoch, width, lane, &ok, stat, mb, &mb_seq);
             epoch++;
             // adapt the width: shrink towards what could be committed, grow back when all of it was
@@ -1726,12 +1757,11 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 low_yield = 0;
         }
 #endif
-        prefer_seq = false;
 #ifdef MRZ_SEQ_PROFILE
         prof_t0 = (int64_t)__builtin_amdgcn_s_memtime();  // the batch booked its own time
 #endif
         if (used == 0 && ok) {
-            stat[MRZ_ST_SEQ] += 1;
+            ST_ADD(MRZ_ST_SEQ, 1);
             // first candidate of the window through the cooperative path
             const int fl = __ffsll((long long)any) - 1;
             const mrz_u64 wl = (mrz_u64)mrz_bcast64((int64_t)w, fl);
@@ -1741,7 +1771,13 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 ok = mrz_seq_candidate(C, L, &batch, mb, &mb_seq, pend_h, pend_t, pend_o, t, lane, stat);
             PROF_ADD(MRZ_ST_T_SEQ);
         }
-        (void)ev_before;
+        if (first_after_emit) {
+            const bool first_was_long = long_seen && used <= 1;
+            int &c = pred_long[emit_cls];
+            c = first_was_long ? (c < 3 ? c + 1 : 3) : (c > 0 ? c - 1 : 0);
+        }
+        after_emit = L.n_events != ev_before;
+        if (after_emit) emit_cls = L.last_len >= MRZ_GREAT_MATCH ? 1 : 0;
     }
 
     // release the helpers, then publish the state for the next segment's launch
@@ -1766,7 +1802,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         st->tag_hits = L.tag_hits;
         st->tag_misses = L.tag_misses;
         st->finished = L.p >= C.end ? 1 : 0;
+#ifdef MRZ_SEQ_STATS
         for (int k = 0; k < MRZ_ST_N; k++) st->prof[k] += stat[k];
+#endif
     }
 }
 
