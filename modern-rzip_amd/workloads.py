@@ -66,3 +66,19 @@ def tar_like(nbytes, seed=5):
         out += mem
         out += bytes((-len(out)) % 512)
     return bytes(out[:nbytes])
+
+
+def stride_stream(nseg, seg_bytes, copy_bytes=None, seed=99):
+    """S4 "stride" shape (BASELINE configs[3], scaled): `nseg` segments of noise (seed + segment index); in every
+    4th segment the first `copy_bytes` (default a quarter) repeat the segment k segments earlier, k cycling
+    through 1, 3, 7 -- long matches at a distance of whole segments."""
+    copy_bytes = seg_bytes // 4 if copy_bytes is None else copy_bytes
+    segs = [np.frombuffer(noise(seg_bytes, seed=seed + i), dtype=np.uint8).copy() for i in range(nseg)]
+    ks = (1, 3, 7)
+    j = 0
+    for i in range(3, nseg, 4):
+        k = ks[j % 3]
+        j += 1
+        if i - k >= 0:
+            segs[i][:copy_bytes] = segs[i - k][:copy_bytes]
+    return b"".join(s.tobytes() for s in segs)

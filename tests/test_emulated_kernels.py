@@ -153,3 +153,11 @@ def test_runzip_many_tiles(emu_lib, oracle):
     assert len(want["s0"]) > 3000
     with m.RzipContext(level=7, max_chunk=len(data), lib=emu_lib) as ctx:
         _parity.check_runzip(ctx, data, want["s0"], want["s1"])
+
+
+def test_stride_repeats(emu_lib, oracle):
+    # BASELINE configs[3] shape in miniature: noise segments, planted repeats 1, 3 and 7 segments back
+    from modern_rzip_amd import workloads as w
+    data = w.stride_stream(12, 4096, copy_bytes=1500)
+    want = _parity.check_chunk(emu_lib, oracle, data)
+    assert want["stats"]["matches"] >= 2

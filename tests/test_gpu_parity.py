@@ -83,6 +83,16 @@ def test_tar_like_mix(gpu_lib, oracle):
     _parity.check_chunk(gpu_lib, oracle, _util.tar_like(8 << 20, seed=5))
 
 
+def test_stride_repeats_unlimited_window(gpu_lib, oracle):
+    """BASELINE configs[3] shape, scaled: noise segments with planted repeats 1, 3 and 7 segments back, one chunk
+    (-U).  Matches are a quarter segment long and reach back up to 7 segments."""
+    data = w.stride_stream(48, 512 << 10)
+    want = _parity.check_chunk(gpu_lib, oracle, data)
+    assert want["stats"]["match_bytes"] >= 10 * (128 << 10)
+    got = _parity.check_file(gpu_lib, oracle, data[: 12 << 20], unlimited=True)
+    assert len(got) < 12 << 20
+
+
 def test_segment_boundaries(gpu_lib, oracle):
     # > 16 Mi positions: the chunk spans two tag-scan segments, with matches crossing the seam
     blk = _util.zipf_text(9 << 20, seed=31)
