@@ -26,6 +26,8 @@ if "noise1" in which: run("noise-1MiB", w.noise(1 << 20))
 if "noise8" in which: run("noise-8MiB", w.noise(8 << 20))
 if "text4" in which: run("text-4MiB", w.zipf_text(4 << 20))
 if "text32" in which: run("text-32MiB", w.zipf_text(32 << 20))
+if "text100" in which: run("text-100MB", w.zipf_text(100_000_000))
+if "noise64" in which: run("noise-64MiB", w.noise(64 << 20))
 if "rep64" in which: run("rep64k-64MiB", w.rep64k_device(1024, "cuda"))
 if "rep1g" in which: run("rep64k-1GiB", w.rep64k_device(16384, "cuda"))
 if "rep10g" in which: run("rep64k-10GiB", w.rep64k_device(163840, "cuda"))
