@@ -563,6 +563,9 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
 #define MRZ_SMAX 16
 #define MRZ_WALK_SLOTS 8   // slots (16 B each) a lane loads per walk step: one 128-B line when aligned
 #define MRZ_WALK_STEPS 12
+#define MRZ_WALK_LANE_STEPS 2   // per-lane steps before long chains may be finished cooperatively
+#define MRZ_WALK_COOP_MAX 6     // ... when at most this many lanes are still walking
+#define MRZ_WALK_COOP_STEPS 2   // 64-slot steps per straggler (16 + 128 slots in all)
 #define MRZ_FILTER_SIZE 4096
 #define MRZ_CULL_WINDOW 4  // x 64 slots scanned ahead of tag_clean_ptr per batch
 
@@ -1171,7 +1174,13 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     {
         bool walking = act;
         int s = h, steps = 0;
-        while (__ballot(walking)) {
+        int ustep = 0;  // per-lane steps taken so far (uniform)
+        while (true) {
+            const mrz_u64 m_walk = __ballot(walking);
+            if (!m_walk) break;
+            // a few long chains left after the first steps: finish those 64 slots at a time (below)
+            if (ustep >= MRZ_WALK_LANE_STEPS && __popcll(m_walk) <= MRZ_WALK_COOP_MAX) break;
+            ustep++;
             if (walking) {
                 mrz_slot e[MRZ_WALK_SLOTS];
 #pragma unroll
@@ -1224,6 +1233,88 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
                 }
             }
         }
+            // ---- stragglers: the rest of a long chain, the whole wave on one lane's chain (64 slots per step).
+        // Same decisions as the per-slot code above, taken on ballots: first empty slot, tag-equal entries
+        // in probe order, and -- while the insert position is still open -- the first slot that is due for
+        // culling or holds a lower-ranked tag, unless max_chain_len tag-equal entries come first.
+        for (mrz_u64 todo = __ballot(walking); todo; todo &= todo - 1) {
+            const int o = __ffsll((long long)todo) - 1;
+            const int64_t t_o = mrz_bcast64(t, o);
+            const int rank_o = mrz_lane_read(my_rank, o);
+            const bool ins_o = mrz_lane_read((int)do_ins, o) != 0;
+            int s_o = mrz_lane_read(s, o), fe_o = -1;
+            int wslot_o = mrz_lane_read(wslot, o), kind_o = mrz_lane_read(kind, o), round_o = mrz_lane_read(round, o);
+            int nsame_o = mrz_lane_read(nsame, o), why_o = mrz_lane_read(why, o);
+            bool evict_o = mrz_lane_read((int)evict, o) != 0, cplx_o = mrz_lane_read((int)cplx, o) != 0;
+            int64_t occ_t_o = mrz_bcast64(occ_t, o), occ_off_o = mrz_bcast64(occ_off, o);
+            for (int cstep = 0; fe_o < 0; cstep++) {
+                if (cstep >= MRZ_WALK_COOP_STEPS) {
+                    cplx_o = true;
+                    if (!why_o) why_o = MRZ_ST_CUT_WALK;
+                    break;
+                }
+                const int slot = (s_o + lane) & smask;
+                const mrz_slot e = tab[slot];
+                const bool empty = (e.off | e.t) == 0;
+                const mrz_u64 m_empty = __ballot(empty);
+                const int fe_idx = m_empty ? __ffsll((long long)m_empty) - 1 : 64;
+                const mrz_u64 valid = mrz_low_mask(fe_idx);
+                const mrz_u64 m_same = __ballot(!empty && e.t == t_o) & valid;
+                if (ins_o && wslot_o < 0 && !evict_o) {
+                    const mrz_u64 m_worse = __ballot(!empty && (e.t & better) != better) & valid;
+                    const mrz_u64 m_lower = __ballot(!empty && mrz_ones_rank(e.t) < rank_o) & valid & ~m_worse;
+                    const mrz_u64 m_stop = m_worse | m_lower;
+                    const int ks = m_stop ? __ffsll((long long)m_stop) - 1 : 64;
+                    const int nq = __popcll(m_same & ~m_worse & mrz_low_mask(ks));
+                    if (round_o + nq >= max_chain) {
+                        evict_o = true;
+                        kind_o = 3;
+                        round_o = max_chain;
+                    } else {
+                        round_o += nq;
+                        if (ks < 64) {
+                            wslot_o = (s_o + ks) & smask;
+                            kind_o = ((m_worse >> ks) & 1) ? 1 : 2;
+                            if (kind_o == 2) {
+                                occ_t_o = mrz_bcast64(e.t, ks);
+                                occ_off_o = mrz_bcast64(e.off, ks);
+                            }
+                        } else if (fe_idx < 64) {
+                            wslot_o = (s_o + fe_idx) & smask;
+                            kind_o = 0;
+                        }
+                    }
+                }
+                if ((m_same >> lane) & 1) {
+                    const int idx = nsame_o + __popcll(m_same & mrz_low_mask(lane));
+                    if (idx < MRZ_SMAX) {
+                        B->same_off[o][idx] = e.off;
+                        B->same_slot[o][idx] = slot;
+                    }
+                }
+                nsame_o += __popcll(m_same);
+                if (nsame_o > MRZ_SMAX) {
+                    cplx_o = true;
+                    if (!why_o) why_o = MRZ_ST_CUT_WALK;
+                }
+                if (fe_idx < 64) fe_o = (s_o + fe_idx) & smask;
+                s_o += 64;
+            }
+            if (lane == o) {
+                walking = false;
+                fe = fe_o;
+                wslot = wslot_o;
+                kind = kind_o;
+                round = round_o;
+                nsame = nsame_o;
+                why = why_o;
+                evict = evict_o;
+                cplx = cplx_o;
+                occ_t = occ_t_o;
+                occ_off = occ_off_o;
+            }
+        }
+        MRZ_WAVE_SYNC();
     }
     if (evict && max_chain > MRZ_SMAX) {
         cplx = true;
@@ -1675,12 +1766,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     int low_yield = 0;         // consecutive batches that committed <= 2 candidates
     int seq_credit = 0;        // candidates to run through the cooperative path before batching again
     // Right after an emission the next candidate often has long matches again (repetitive input): a batch
-    // would be formed, walked and probed only to be cut at its first lane.  Two saturating counters, one per
-    // class of the emitted match (short / >= GREAT_MATCH), learn whether that is so; when it is, the first
-    // candidate after an emission goes straight through the cooperative path.
+    // would be formed, walked and probed only to be cut at its first lane.  Four saturating counters, indexed by
+    // the classes (short / >= GREAT_MATCH) of the last two emitted matches, learn whether that is so; when it
+    // is, the first candidate after an emission goes straight through the cooperative path.
     bool after_emit = false;
-    int emit_cls = 0;
-    int pred_long[2] = { 0, 0 };
+    int emit_cls = 0;  // bit 0: last emitted match was great, bit 1: the one before
+    int pred_long[4] = { 0, 0, 0, 0 };
 #ifdef MRZ_SEQ_STATS
     int64_t stat[MRZ_ST_N];
     for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
@@ -1777,7 +1868,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             c = first_was_long ? (c < 3 ? c + 1 : 3) : (c > 0 ? c - 1 : 0);
         }
         after_emit = L.n_events != ev_before;
-        if (after_emit) emit_cls = L.last_len >= MRZ_GREAT_MATCH ? 1 : 0;
+        if (after_emit) emit_cls = ((emit_cls << 1) & 2) | (L.last_len >= MRZ_GREAT_MATCH ? 1 : 0);
     }
 
     // release the helpers, then publish the state for the next segment's launch
