@@ -563,8 +563,12 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
 #define MRZ_SMAX 16
 #define MRZ_WALK_SLOTS 8   // slots (16 B each) a lane loads per walk step: one 128-B line when aligned
 #define MRZ_WALK_STEPS 12
+#ifndef MRZ_WALK_LANE_STEPS
 #define MRZ_WALK_LANE_STEPS 2   // per-lane steps before long chains may be finished cooperatively
+#endif
+#ifndef MRZ_WALK_COOP_MAX
 #define MRZ_WALK_COOP_MAX 6     // ... when at most this many lanes are still walking
+#endif
 #define MRZ_WALK_COOP_STEPS 2   // 64-slot steps per straggler (16 + 128 slots in all)
 #define MRZ_FILTER_SIZE 4096
 #define MRZ_CULL_WINDOW 4  // x 64 slots scanned ahead of tag_clean_ptr per batch
@@ -1330,7 +1334,12 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         const int rank2 = mrz_ones_rank(occ_t);
         h2 = (int)(occ_t & C.slot_mask);
         int s = h2, steps = 0, round2 = 0;
-        while (__ballot(walking)) {
+        int ustep = 0;
+        while (true) {
+            const mrz_u64 m_walk = __ballot(walking);
+            if (!m_walk) break;
+            if (ustep >= MRZ_WALK_LANE_STEPS && __popcll(m_walk) <= MRZ_WALK_COOP_MAX) break;
+            ustep++;
             if (walking) {
                 mrz_slot e[MRZ_WALK_SLOTS];
 #pragma unroll
@@ -1365,6 +1374,57 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
                     if (!why) why = MRZ_ST_CUT_WALK;
                     walking = false;
                 }
+            }
+        }
+        // stragglers, 64 slots per step: first of {empty, due for culling, lower-ranked} decides, unless
+        // max_chain_len entries with the occupant's tag come first (then, as for a lower-ranked slot, the
+        // cascade goes to the cooperative path)
+        for (mrz_u64 todo = __ballot(walking); todo; todo &= todo - 1) {
+            const int o = __ffsll((long long)todo) - 1;
+            const int64_t ot = mrz_bcast64(occ_t, o);
+            const int rk = mrz_lane_read(rank2, o);
+            int s_o = mrz_lane_read(s, o), r2 = mrz_lane_read(round2, o);
+            int w2_o = -1, kind2_o = -1, why_o = mrz_lane_read(why, o);
+            bool cplx_o = false, done = false;
+            for (int cstep = 0; !done; cstep++) {
+                if (cstep >= MRZ_WALK_COOP_STEPS) {
+                    cplx_o = true;
+                    if (!why_o) why_o = MRZ_ST_CUT_WALK;
+                    break;
+                }
+                const int slot = (s_o + lane) & smask;
+                const mrz_slot e = tab[slot];
+                const bool empty = (e.off | e.t) == 0;
+                const bool worse = !empty && (e.t & better) != better;
+                const bool lower = !empty && !worse && mrz_ones_rank(e.t) < rk;
+                const mrz_u64 m_empty = __ballot(empty), m_worse = __ballot(worse), m_lower = __ballot(lower);
+                const mrz_u64 m_stop = m_empty | m_worse | m_lower;
+                const int ks = m_stop ? __ffsll((long long)m_stop) - 1 : 64;
+                const int nq = __popcll(__ballot(!empty && !worse && !lower && e.t == ot) & mrz_low_mask(ks));
+                if (r2 + nq >= max_chain) {
+                    cplx_o = true;
+                    if (!why_o) why_o = MRZ_ST_CUT_CASCADE;
+                    done = true;
+                } else if (ks < 64) {
+                    if ((m_lower >> ks) & 1) {
+                        cplx_o = true;  // second-level displacement: cooperative path
+                        if (!why_o) why_o = MRZ_ST_CUT_CASCADE;
+                    } else {
+                        w2_o = (s_o + ks) & smask;
+                        kind2_o = ((m_empty >> ks) & 1) ? 0 : 1;
+                    }
+                    done = true;
+                } else {
+                    r2 += nq;
+                    s_o += 64;
+                }
+            }
+            if (lane == o) {
+                walking = false;
+                w2 = w2_o;
+                kind2 = kind2_o;
+                if (cplx_o) cplx = true;
+                why = why_o;
             }
         }
         if (w2 >= 0) len2 = ((w2 - h2) & smask) + 1;
