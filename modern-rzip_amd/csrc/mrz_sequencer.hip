@@ -445,8 +445,9 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 // instruction; results come back the same way, one word per helper.  The mailbox is zeroed by
 // the host before every launch and a launch runs fewer than 2^24 rounds, so a tag never
 // repeats.  Helpers take a ticket when they start; the leader only addresses tickets it has
-// seen, so the scheme does not depend on every workgroup of the grid being resident.  The
-// compared bytes themselves are read-only input.  All spins are bounded.
+// seen, so the scheme does not depend on every workgroup of the grid being resident; if an
+// answer does not arrive in ~0.5 s the leader gives the farm up for the launch and compares
+// locally.  The compared bytes themselves are read-only input.  All spins are bounded.
 #ifndef MRZ_HELPER_WGS
 #define MRZ_HELPER_WGS 240  // most of the 256 CUs; the launcher may ask for fewer
 #endif
@@ -457,7 +458,8 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #define MRZ_FARM_SHIFT 40
 #define MRZ_FARM_PAYLOAD ((1ull << MRZ_FARM_SHIFT) - 1)
 #define MRZ_FARM_NONE MRZ_FARM_PAYLOAD
-#define MRZ_SPIN_LIMIT (1 << 22)          // leader: ~1 s of polling for an answer that takes microseconds
+#define MRZ_SPIN_LIMIT (1 << 20)          // leader: ~0.5 s of polling for an answer that takes microseconds; then
+                                           // the farm is given up for this launch and the compare is done locally
 #define MRZ_HELPER_SPIN_LIMIT (1ll << 34)  // helpers: idle for as long as a launch may run
 
 struct mrz_gmailbox {
@@ -841,7 +843,9 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
             if (watch_rev) ok = ok && (rv >> MRZ_FARM_SHIFT) == seq;
             if (__ballot(!ok) == 0) break;
             if (spins++ >= MRZ_SPIN_LIMIT) {
-                if (lane == 0) C.st->error = 3;  // helpers never answered
+                // helpers never answered (preempted, not resident): no more farm rounds in this launch.  A late
+                // answer carries this round's number and is never looked at again.
+                *C.gnw = -1;
                 return false;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -879,7 +883,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
 
 // refresh the count of helpers that have started (only until all of them have)
 __device__ __forceinline__ void mrz_farm_census(const mrz_cfg &C) {
-    if (C.gmb && *C.gnw < C.n_helpers) {
+    if (C.gmb && *C.gnw >= 0 && *C.gnw < C.n_helpers) {
         int seen = (int)mrz_uni64((int64_t)mrz_g_loadu(&C.gmb->ready));
         if (seen > C.n_helpers) seen = C.n_helpers;
         *C.gnw = seen;
@@ -914,15 +918,15 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
         mrz_farm_census(C);
         if (*C.gnw >= 2 * MRZ_FARM_ENTRIES && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
             int64_t fw, rv;
-            if (!mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
-                          &rv))
-                return false;
-            if (my_r < 0) {
-                my_ml = my_op < qx ? fw + rv : 0;
-                my_rv = rv;
-                if (my_ml < MRZ_MIN_MATCH) my_ml = 0;
-            }
-            farmed = true;
+            if (mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
+                         &rv)) {
+                if (my_r < 0) {
+                    my_ml = my_op < qx ? fw + rv : 0;
+                    my_rv = rv;
+                    if (my_ml < MRZ_MIN_MATCH) my_ml = 0;
+                }
+                farmed = true;
+            }  // else: the farm gave up, everything is measured locally below
         }
     }
 #endif
@@ -942,11 +946,12 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
             if (ml < 0) {
                 // still equal after the local round: the rest of the forward compare goes to the farm
                 int64_t fw, dummy;
-                if (!mrz_farm(C, B, qx, C.end - qx, floor_p, cont, 1, op, true, false, lane, stat, &fw, &dummy))
-                    return false;
-                fw = mrz_bcast64(fw, 0);
-                ml = fw + rv;
-                if (ml < MRZ_MIN_MATCH) ml = 0;
+                if (mrz_farm(C, B, qx, C.end - qx, floor_p, cont, 1, op, true, false, lane, stat, &fw, &dummy)) {
+                    fw = mrz_bcast64(fw, 0);
+                    ml = fw + rv;
+                    if (ml < MRZ_MIN_MATCH) ml = 0;
+                } else  // the farm gave up: all of it locally
+                    ml = mrz_long_match_len(buf, mb, mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat, nullptr);
             }
 #endif
             if (lane == k) {

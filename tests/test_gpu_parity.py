@@ -16,6 +16,7 @@ from tests import _parity, _util
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 with open(os.path.join(HERE, "golden", "vectors.json")) as f:
     GOLD = json.load(f)
 
@@ -91,6 +92,25 @@ def test_stride_repeats_unlimited_window(gpu_lib, oracle):
     assert want["stats"]["match_bytes"] >= 10 * (128 << 10)
     got = _parity.check_file(gpu_lib, oracle, data[: 12 << 20], unlimited=True)
     assert len(got) < 12 << 20
+
+
+@pytest.mark.parametrize("farm_wgs", ["0", "40"])
+def test_small_or_no_compare_farm(farm_wgs):
+    """The helper-workgroup count is a launch parameter: without helpers (local striped compares only) and with
+    a two-row farm the streams must be the same bits.  Own process: the count is read once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import modern_rzip_amd as m\n"
+        "from tests import _parity, _util\n"
+        "import os\n"
+        "o = _util.Oracle(os.path.join(%r, 'oracle', 'liboracle.so'))\n"
+        "_parity.check_chunk(m.load_library(), o, _util.rep64k(160, seed=21))\n"
+        "print('ok')\n" % (ROOT, ROOT))
+    env = dict(os.environ, MRZ_FARM_WGS=farm_wgs)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_segment_boundaries(gpu_lib, oracle):
