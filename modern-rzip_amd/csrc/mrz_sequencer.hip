@@ -56,10 +56,10 @@
 #define MRZ_HAVE_SCOUT (MRZ_SEQ_WAVES > 2)
 #define MRZ_CASCADE_MAX 64
 #ifndef MRZ_SEQ_CREDIT
-#define MRZ_SEQ_CREDIT 16      // candidates sent through the cooperative path after repeated tiny batches
+#define MRZ_SEQ_CREDIT 8       // candidates sent through the cooperative path after repeated tiny batches
 #endif
 #ifndef MRZ_LOW_YIELD_RUNS
-#define MRZ_LOW_YIELD_RUNS 3
+#define MRZ_LOW_YIELD_RUNS 2
 #endif
 
 // optional in-kernel cycle accounting (diagnostic builds only: -DMRZ_SEQ_PROFILE)
@@ -452,7 +452,18 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #define MRZ_HELPER_WGS 240  // most of the 256 CUs; the launcher may ask for fewer
 #endif
 #define MRZ_FARM_ENTRIES 16
+#ifndef MRZ_FARM_WAVE_BYTES
 #define MRZ_FARM_WAVE_BYTES 2048
+#endif
+#ifndef MRZ_FARM_HELPER_SLEEP
+#define MRZ_FARM_HELPER_SLEEP 2
+#endif
+#ifndef MRZ_FARM_LEADER_SLEEP
+#define MRZ_FARM_LEADER_SLEEP 1
+#endif
+#ifndef MRZ_FARM_HINT_MIN
+#define MRZ_FARM_HINT_MIN 8192  // single long entry: farm first when the last long match reached this far
+#endif
 #define MRZ_FARM_SPW (MRZ_SEQ_WAVES * MRZ_FARM_WAVE_BYTES)  // bytes of each stream per helper and round
 #define MRZ_FARM_GMAX 32
 #define MRZ_FARM_SHIFT 40
@@ -520,7 +531,7 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
                     if (lane == 8 + MRZ_FARM_ENTRIES) s_job[par][lane] = giveup ? ~0ull : tag0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(MRZ_FARM_HELPER_SLEEP);
             }
         }
         __syncthreads();
@@ -848,7 +859,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
                 *C.gnw = -1;
                 return false;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(MRZ_FARM_LEADER_SLEEP);
         }
         {
             int seen = (int)mrz_bcast64((int64_t)ready, 63);
@@ -916,7 +927,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
 #if MRZ_HELPER_WGS > 0
     if (nlong && C.gmb && nsx <= MRZ_FARM_ENTRIES) {
         mrz_farm_census(C);
-        if (*C.gnw >= 2 * MRZ_FARM_ENTRIES && (nlong >= 2 || *C.farm_hint >= (int64_t)MRZ_STRIPE_WAVES * MRZ_STRIPE)) {
+        if (*C.gnw >= 2 * MRZ_FARM_ENTRIES && (nlong >= 2 || *C.farm_hint >= MRZ_FARM_HINT_MIN)) {
             int64_t fw, rv;
             if (mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
                          &rv)) {
