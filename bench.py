@@ -179,7 +179,7 @@ def main():
         }
         if verify:
             out["verify"] = verify
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(int(min(args.cpu_sample_gib, args.gib) * GIB))
         print(json.dumps(out), flush=True)
     ctx.close()
