@@ -32,6 +32,9 @@
 #define MRZ_LZ_MAXDIST 65535
 #define MRZ_LZ_64K_LIMIT (65536 + 11)
 #define MRZ_LZ_STREAM_MIN (10 * 1048576)
+#ifndef MRZ_LZ_FIRST_WIDTH
+#define MRZ_LZ_FIRST_WIDTH 16  // probes in the first batch of a search
+#endif
 
 __device__ __forceinline__ uint32_t mrz_lz_hash(const uint8_t *p, bool small) {
     if (small) return (mrz_ld4(p) * 2654435761u) >> (32 - 13);
@@ -91,19 +94,23 @@ __device__ static int mrz_lz4_size_wave(const uint8_t *__restrict__ src, int n, 
         int k0 = 0;
         int64_t match = 0;
         bool found = false;
+        // compressible data finds its match within a few probes: the first batch of a search is 16 probes wide
+        // (the all-pairs forwarding below costs `width` shuffle rounds), later ones 64
+        int width = MRZ_LZ_FIRST_WIDTH;
         while (true) {
             const int k = k0 + lane;
-            const int my_step = k == 0 ? 1 : (63 + k) >> 6;
+            const bool active = lane < width;
+            const int my_step = !active ? 0 : (k == 0 ? 1 : (63 + k) >> 6);
             const int incl = mrz_wave_incl_sum(my_step, lane);
             const int64_t pos = pos0 + (incl - my_step);
             const int64_t nxt = pos + my_step;
-            const bool runs = nxt <= mfl1;  // this probe gets past `if (fwd > mflimitPlusOne) goto _last_literals`
-            uint32_t h = 0;
+            const bool runs = active && nxt <= mfl1;  // this probe gets past `if (fwd > mflimitPlusOne) goto _last_literals`
+            uint32_t h = 0xffffffffu;  // inactive lanes never equal a real cell index
             if (runs) h = mrz_lz_hash(src + pos, small);
             // table value seen by this probe: old cell unless an earlier probe of the batch wrote it
             uint32_t mi = runs ? tab[h] : 0;
             int next_same = 64;
-            for (int j = 0; j < 64; j++) {
+            for (int j = 0; j < width; j++) {
                 const uint32_t hj = (uint32_t)__shfl((int)h, j, MRZ_WAVE);
                 const uint32_t pj = (uint32_t)__shfl((int)(uint32_t)pos, j, MRZ_WAVE);
                 if (hj == h) {
@@ -116,9 +123,9 @@ __device__ static int mrz_lz4_size_wave(const uint8_t *__restrict__ src, int n, 
                 const bool near = small || ((int64_t)mi + MRZ_LZ_MAXDIST >= pos);
                 hit = near && mrz_ld4(src + mi) == mrz_ld4(src + pos);
             }
-            const mrz_u64 m_end = __ballot(!runs);
+            const mrz_u64 m_end = __ballot(active && !runs);
             const mrz_u64 m_hit = __ballot(hit);
-            const int first_end = m_end ? __ffsll((long long)m_end) - 1 : 64;
+            const int first_end = m_end ? __ffsll((long long)m_end) - 1 : width;
             const int first_hit = m_hit ? __ffsll((long long)m_hit) - 1 : 64;
             // probes [0, last_run] executed their table update
             int last_run;
@@ -133,9 +140,10 @@ __device__ static int mrz_lz4_size_wave(const uint8_t *__restrict__ src, int n, 
                 found = true;
                 break;
             }
-            if (first_end < 64) break;  // ran out of input: last literals
-            pos0 = mrz_bcast64(nxt, 63);
-            k0 += 64;
+            if (first_end < width) break;  // ran out of input: last literals
+            pos0 = mrz_bcast64(nxt, width - 1);
+            k0 += width;
+            width = 64;
         }
         if (!found) {
             to_tail = true;
