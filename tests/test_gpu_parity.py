@@ -124,6 +124,17 @@ def test_long_match_pieces_and_backward(gpu_lib, oracle):
     _parity.check_chunk(gpu_lib, oracle, blk + blk + b"xyz" + blk[5:] + blk)
 
 
+def test_farm_multi_round_matches(gpu_lib, oracle):
+    """Matches far longer than one farm round covers (224 KiB per entry and round): several tag-equal entries that
+    are all ~700 KB long (rounds continue until the last entry stops), a lone long entry (local round, then the
+    farm), and a match that runs into the end of the chunk."""
+    blk = _util.xorshift_noise(700000, seed=31)
+    tail = _util.xorshift_noise(900, seed=32)
+    data = blk + b"#" + blk + b"##" + blk + b"###" + blk[:650000] + tail + blk[1000:]
+    want = _parity.check_chunk(gpu_lib, oracle, data)
+    assert want["stats"]["match_bytes"] > 3 * 600000
+
+
 def test_multi_chunk_file(gpu_lib, oracle):
     data = _util.rep64k(96, seed=13)  # 6 MiB, chunks of 2 MiB+
     _parity.check_file(gpu_lib, oracle, data, ramsize=3 * (2 << 20) // 2 + 5000)
