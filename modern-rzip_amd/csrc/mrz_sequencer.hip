@@ -1507,7 +1507,7 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
     const mrz_u64 m_evict = __ballot(ins && kind == 3);
     if (ins && kind == 3) {
         const int er = __popcll(m_evict & mrz_low_mask(lane));
-        const int vr = (int)((L.victim_round + er) % max_chain);
+        const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
         wslot = B->same_slot[lane][vr];
     }
     // hash_count before each lane: saturating prefix sum of the per-lane deltas
@@ -1726,7 +1726,8 @@ __device__ static int mrz_batch_step(const mrz_cfg &C, mrz_lead &L, mrz_batch_ld
         L.clean_ptr = mrz_lane_read(cslot, lastc);
         L.tag_mask = better;
     }
-    L.victim_round = (L.victim_round + __popcll(m_evict & keep)) % max_chain;
+    if (m_evict & keep)  // 32-bit arithmetic: both operands are small, a 64-bit modulo is ~200 instructions
+        L.victim_round = (int64_t)(((unsigned)L.victim_round + (unsigned)__popcll(m_evict & keep)) % (unsigned)max_chain);
     const int hsum = mrz_wave_incl_sum(mine ? hits : 0, lane);
     const int msum = mrz_wave_incl_sum(mine ? misses : 0, lane);
     L.tag_hits += mrz_lane_read(hsum, 63);
