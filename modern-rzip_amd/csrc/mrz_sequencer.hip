@@ -604,100 +604,81 @@ __device__ __forceinline__ unsigned mrz_filter_slot(int slot) {
     return ((unsigned)(slot >> 6) * 2654435761u) >> 20;  // 12 bits
 }
 
-// per-lane forward/backward extension of one candidate, 64 B reach each way
+// branch-free versions of mrz_first_diff16 / mrz_top_equal16: this code runs per lane with diverging data, and
+// every early return there is an EXEC-mask branch (the branchy form of mrz_lane_match_len was ~740 instructions,
+// a third of them control flow)
+__device__ __forceinline__ int mrz_first_diff16_bf(uint4 a, uint4 b) {
+    const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+    int r = 16;
+    r = d3 ? 12 + ((__ffs((int)d3) - 1) >> 3) : r;
+    r = d2 ? 8 + ((__ffs((int)d2) - 1) >> 3) : r;
+    r = d1 ? 4 + ((__ffs((int)d1) - 1) >> 3) : r;
+    r = d0 ? ((__ffs((int)d0) - 1) >> 3) : r;
+    return r;
+}
+__device__ __forceinline__ int mrz_top_equal16_bf(uint4 a, uint4 b) {
+    const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+    int r = 16;
+    r = d0 ? 12 + (__clz((int)d0) >> 3) : r;
+    r = d1 ? 8 + (__clz((int)d1) >> 3) : r;
+    r = d2 ? 4 + (__clz((int)d2) >> 3) : r;
+    r = d3 ? (__clz((int)d3) >> 3) : r;
+    return r;
+}
+
+// per-lane forward/backward extension of one candidate (single_match_len, src/rzip.c:372-397), 64 B reach each
+// way: all sixteen 16-byte pieces are loaded at once (addresses clamped into the chunk; what a clamped piece
+// holds never matters because the counts are capped by maxf / maxb), then evaluated without branches.  A match
+// that runs past the reach -- or whose backward part touches the first bytes of the chunk, where a 16-byte piece
+// cannot be loaded -- is reported as `is_long` and measured exactly by the cooperative / farm path.
 __device__ static void mrz_lane_match_len(const uint8_t *__restrict__ buf, int64_t q, int64_t op, int64_t end,
                                           int64_t last_match, int64_t *len, int64_t *rev, bool *is_long) {
     *len = 0;
     *rev = 0;
     *is_long = false;
     if (op >= q) return;
-    const int64_t maxf = end - q;
+    int64_t maxf = end - q;
+    if (maxf < 0) maxf = 0;
     const int64_t floor_p = last_match > 0 ? last_match : 0;
     int64_t maxb = q - floor_p;
     if (op < maxb) maxb = op;
-    // the first backward piece is loaded together with the forward pieces: one round trip
-    uint4 rb_a = make_uint4(0, 0, 0, 0), rb_b = make_uint4(0, 0, 0, 0);
-    const bool rb_wide = maxb > 0 && op - 16 >= 0;
-    if (rb_wide) {
-        rb_a = mrz_ld16(buf + q - 16);
-        rb_b = mrz_ld16(buf + op - 16);
-    }
-    int64_t fwd = 0;
-    bool lng = false;
-    if (maxf > 0) {
-        uint4 a[4], b[4];
+    if (maxb < 0) maxb = 0;
+    const int64_t last_ok = end + (MRZ_MIN_MATCH - 16);  // chunk size - 16: the last 16-byte piece inside the chunk
+    uint4 fa[4], fb[4], ba[4], bb[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if ((int64_t)j * 16 < maxf) {
-                a[j] = mrz_ld16(buf + q + j * 16);
-                b[j] = mrz_ld16(buf + op + j * 16);
-            }
-        bool stop = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (stop) continue;
-            const int64_t off = (int64_t)j * 16;
-            if (off >= maxf) {
-                fwd = maxf;
-                stop = true;
-                continue;
-            }
-            const int64_t rem = maxf - off;
-            const int lim = rem < 16 ? (int)rem : 16;
-            const int d = mrz_first_diff16(a[j], b[j]);
-            const int ll = d < lim ? d : lim;
-            if (ll < 16) {
-                fwd = off + ll;
-                stop = true;
-            }
-        }
-        if (!stop) {
-            if (maxf <= 64)
-                fwd = maxf;
-            else
-                lng = true;
-        }
+    for (int j = 0; j < 4; j++) {
+        int64_t pa = q + j * 16, pb = op + j * 16;
+        pa = pa < last_ok ? pa : last_ok;
+        pb = pb < last_ok ? pb : last_ok;
+        fa[j] = mrz_ld16(buf + pa);
+        fb[j] = mrz_ld16(buf + pb);
+        int64_t ra = q - (j + 1) * 16, rb = op - (j + 1) * 16;
+        ra = ra > 0 ? ra : 0;
+        rb = rb > 0 ? rb : 0;
+        ba[j] = mrz_ld16(buf + ra);
+        bb[j] = mrz_ld16(buf + rb);
     }
-    int64_t rv = 0;
-    if (maxb > 0 && !lng) {
-        bool stop = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (stop) continue;
-            const int64_t off = (int64_t)j * 16;
-            if (off >= maxb) {
-                rv = maxb;
-                stop = true;
-                continue;
-            }
-            const int64_t rem = maxb - off;
-            const int lim = rem < 16 ? (int)rem : 16;
-            int cnt;
-            if (j == 0 && rb_wide)
-                cnt = mrz_top_equal16(rb_a, rb_b);
-            else if (op - off - 16 >= 0)
-                cnt = mrz_top_equal16(mrz_ld16(buf + q - off - 16), mrz_ld16(buf + op - off - 16));
-            else {
-                cnt = 0;
-                while (cnt < lim && buf[q - off - 1 - cnt] == buf[op - off - 1 - cnt]) cnt++;
-            }
-            const int ll = cnt < lim ? cnt : lim;
-            if (ll < 16) {
-                rv = off + ll;
-                stop = true;
-            }
-        }
-        if (!stop) {
-            if (maxb <= 64)
-                rv = maxb;
-            else
-                lng = true;
-        }
+    // forward: equal bytes among the first 64
+    int rawf;
+    {
+        const int d0 = mrz_first_diff16_bf(fa[0], fb[0]), d1 = mrz_first_diff16_bf(fa[1], fb[1]);
+        const int d2 = mrz_first_diff16_bf(fa[2], fb[2]), d3 = mrz_first_diff16_bf(fa[3], fb[3]);
+        rawf = d0 < 16 ? d0 : 16 + (d1 < 16 ? d1 : 16 + (d2 < 16 ? d2 : 16 + d3));
     }
-    if (lng) {
-        *is_long = true;
-        return;
+    const int64_t fwd = rawf < maxf ? rawf : maxf;
+    bool lng = rawf == 64 && maxf > 64;
+    // backward: pieces at or beyond `edge` would start before byte 0 of the chunk
+    const int edge = op < 64 ? (int)(op >> 4) : 4;
+    int rawb;
+    {
+        const int e0 = edge > 0 ? mrz_top_equal16_bf(ba[0], bb[0]) : 16, e1 = edge > 1 ? mrz_top_equal16_bf(ba[1], bb[1]) : 16;
+        const int e2 = edge > 2 ? mrz_top_equal16_bf(ba[2], bb[2]) : 16, e3 = edge > 3 ? mrz_top_equal16_bf(ba[3], bb[3]) : 16;
+        rawb = e0 < 16 ? e0 : 16 + (e1 < 16 ? e1 : 16 + (e2 < 16 ? e2 : 16 + e3));
     }
+    const int64_t rv = rawb < maxb ? rawb : maxb;
+    lng = lng || (rawb == 64 && maxb > 64) || (edge < 4 && rawb >= 16 * edge && maxb > 16 * edge);
+    *is_long = lng;
+    if (lng) return;
     *rev = rv;
     const int64_t l = fwd + rv;
     *len = l >= MRZ_MIN_MATCH ? l : 0;
