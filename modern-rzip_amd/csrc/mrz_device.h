@@ -66,6 +66,13 @@ __device__ __forceinline__ int64_t mrz_bcast64(int64_t v, int src) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// per-lane source index (unlike mrz_bcast64, whose source is wave-uniform)
+__device__ __forceinline__ int64_t mrz_shfl64(int64_t v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)(uint64_t)v, src, MRZ_WAVE);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)v >> 32), src, MRZ_WAVE);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int64_t mrz_shfl_xor64(int64_t v, int d) {
     const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)v, d, MRZ_WAVE);
     const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), d, MRZ_WAVE);

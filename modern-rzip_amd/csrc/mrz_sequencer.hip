@@ -433,9 +433,11 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 // CU keeps only ~8 KiB of loads in flight (~20 GB/s on cold data), so the compares are spread
 // over the whole chip: the grid carries helper workgroups (one per CU: 512 threads x 256 VGPRs
 // fill a CU) that wait on a mailbox in device memory.  A round compares, for every pending
-// entry e, G consecutive 16 KiB stripes: helper ticket w takes stripe w >> 4 of entry w & 15
-// (2 KiB per wave) and reports where the compare stops inside its stripe, or "equal
-// throughout"; the row of helpers after the forward rows measures the backward halves.
+// entry, G consecutive stripes: the pending entries are compacted into 2^c columns, helper
+// ticket w takes stripe w >> c of column w & (2^c - 1) (16 KiB, from the second round on
+// 64-128 KiB; 2 KiB per wave and step) and reports where the compare stops inside its stripe,
+// or "equal throughout"; the row of helpers after the forward rows measures the backward
+// halves.  A single entry that is still equal after the first round gets all helpers.
 //
 // Hand-off protocol.  Every mailbox word carries the round number in its top 24 bits and the
 // payload (an offset < 2^40) in the low 40, is written with ONE agent-scope (sc1) atomic store
@@ -465,7 +467,8 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #define MRZ_FARM_HINT_MIN 8192  // single long entry: farm first when the last long match reached this far
 #endif
 #define MRZ_FARM_SPW (MRZ_SEQ_WAVES * MRZ_FARM_WAVE_BYTES)  // bytes of each stream per helper and round
-#define MRZ_FARM_GMAX 32
+#define MRZ_FARM_GMAX 255  // rows fit the 8-bit field of the job word
+#define MRZ_FARM_ROWS0 14  // forward rows of a first round
 #define MRZ_FARM_SHIFT 40
 #define MRZ_FARM_PAYLOAD ((1ull << MRZ_FARM_SHIFT) - 1)
 #define MRZ_FARM_NONE MRZ_FARM_PAYLOAD
@@ -508,7 +511,6 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
     __syncthreads();
     const int me = (int)s_job[0][25];  // my ticket
     if (me >= MRZ_HELPER_WGS) return;
-    const int e = me & (MRZ_FARM_ENTRIES - 1), s = me >> 4;  // entry column, stripe row
     unsigned long long seen = 0;
     int par = 0;
     while (true) {
@@ -538,11 +540,13 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
         const unsigned long long tag = s_job[par][8 + MRZ_FARM_ENTRIES];
         if (tag == ~0ull) return;
         seen = tag;
+        // cfg: columns (log2) | forward rows << 8 | want_rev << 16 | sub-stripes per helper << 24
         const int cfg = (int)s_job[par][4];
-        const int nsx = cfg & 0xff, G = (cfg >> 8) & 0xff;
+        const int lgc = cfg & 0xff, G = (cfg >> 8) & 0xff, mult = (cfg >> 24) & 0xff;
         const bool want_rev = (cfg >> 16) & 1;
-        const bool bwd_job = want_rev && s == G;  // the row after the forward rows goes backward
-        if (e >= nsx || (s >= G && !bwd_job)) continue;
+        const int e = me & ((1 << lgc) - 1), s = me >> lgc;  // column = slot of a pending entry, stripe row
+        const bool bwd_job = want_rev && s == G;              // the row after the forward rows goes backward
+        if (s >= G && !bwd_job) continue;
         const int64_t p0 = (int64_t)s_job[par][0], op = (int64_t)s_job[par][8 + e];
         if (op >= p0) continue;
         if (bwd_job) {
@@ -557,8 +561,14 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
             continue;
         }
         const int64_t maxf = (int64_t)s_job[par][1], base = (int64_t)s_job[par][3];
-        const int64_t off0 = base + (int64_t)s * MRZ_FARM_SPW + (int64_t)wave * MRZ_FARM_WAVE_BYTES;
-        const int64_t r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf, off0, lane);
+        // this helper's stripe: mult x 16 KiB, each wave mult x 2 KiB of it, 2 KiB at a time until a difference
+        int64_t r = -1;
+        {
+            const int64_t off0 = base + (int64_t)s * mult * MRZ_FARM_SPW + (int64_t)wave * mult * MRZ_FARM_WAVE_BYTES;
+            for (int k = 0; k < mult && r < 0; k++)
+                r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf,
+                                                                      off0 + (int64_t)k * MRZ_FARM_WAVE_BYTES, lane);
+        }
         // the last wave to arrive publishes the workgroup's answer (no barrier)
         if (lane == 0) {
             if (r >= 0) atomicMin(&s_min, (unsigned long long)r);
@@ -789,37 +799,53 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
 #endif
     mrz_u64 pending = __ballot(my_pending && lane < nsx);
     int64_t fwd = 0, rev = 0;
+    int rounds = 0;
     while (pending) {
-        // helper ticket w works on entry w & 15, stripe row w >> 4; rows 0..G-1 go forward, row G backward
-        int G = (*C.gnw >> 4) - (want_rev ? 1 : 0);
+        // The pending entries are compacted into the first `np` columns; helper ticket w works on column
+        // w & (ncols - 1), stripe row w >> lgc.  Rows 0..G-1 go forward, row G backward (first round only).
+        // From the second round on every helper takes several 16 KiB sub-stripes: entries that are still equal
+        // are long, and a match of gigabytes (a stream that repeats itself exactly) should move at HBM speed.
+        const int np = __popcll(pending);
+        int lgc = 0;
+        while ((1 << lgc) < np) lgc++;
+        const int ncols = 1 << lgc;
+        int G = (*C.gnw >> lgc) - (want_rev ? 1 : 0);
         if (G > MRZ_FARM_GMAX) G = MRZ_FARM_GMAX;
-        const int nass = G << 4;
+        // first round: most matches end within 224 KiB, and every extra helper is one more answer to wait for
+        if (rounds == 0 && G > MRZ_FARM_ROWS0) G = MRZ_FARM_ROWS0;
+        const int mult = rounds == 0 ? 1 : (rounds == 1 ? 4 : 8);
+        const int nass = G << lgc;
+        const int my_col = __popcll(pending & mrz_low_mask(lane));  // column of entry `lane` (if pending)
+        const bool mine = lane < nsx && ((pending >> lane) & 1);
         *C.gseq += 1;
         const unsigned long long seq = *C.gseq;
         // post: one store instruction carries the whole job
         {
-            const int src = (lane - 8) & 63;
-            const int64_t op_of = __shfl(my_op, src, MRZ_WAVE);
+            const int col = lane - 8;  // lanes 8..23 carry the entry offsets by column
+            if (mine) B->farm_min[my_col] = (unsigned long long)my_op;  // compaction through LDS
+            MRZ_WAVE_SYNC();
+            const int64_t op_of = (col >= 0 && col < np) ? (int64_t)B->farm_min[col] : 0;
+            MRZ_WAVE_SYNC();
             unsigned long long v = 0;
             if (lane == 0) v = (unsigned long long)p0;
             if (lane == 1) v = (unsigned long long)(maxf > 0 ? maxf : 0);
             if (lane == 2) v = (unsigned long long)floor_p;
             if (lane == 3) v = (unsigned long long)base;
-            if (lane == 4) v = (unsigned long long)(nsx | (G << 8) | ((want_rev ? 1 : 0) << 16));
-            if (lane >= 8) v = (unsigned long long)((src < nsx && ((pending >> src) & 1)) ? op_of : p0);
+            if (lane == 4) v = (unsigned long long)(lgc | (G << 8) | ((want_rev ? 1 : 0) << 16) | (mult << 24));
+            if (lane >= 8) v = (unsigned long long)((col < np) ? op_of : p0);
             if (lane < 8 + MRZ_FARM_ENTRIES) mrz_g_storeu(&g->words[lane], (seq << MRZ_FARM_SHIFT) | v);
         }
         PROF_ADD(MRZ_ST_F_POST);
         // which result words this lane watches
-        int ent[4];
+        int colw[4];
         bool watch[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int w = lane + 64 * j;
-            ent[j] = w & (MRZ_FARM_ENTRIES - 1);
-            watch[j] = w < nass && ent[j] < nsx && ((pending >> ent[j]) & 1);
+            colw[j] = w & (ncols - 1);
+            watch[j] = w < nass && colw[j] < np;
         }
-        const bool watch_rev = want_rev && lane < nsx && ((pending >> lane) & 1);
+        const bool watch_rev = want_rev && mine;
         unsigned long long val[4] = { 0, 0, 0, 0 }, rv = 0, ready = 0;
         int spins = 0;
         while (true) {
@@ -827,7 +853,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (watch[j]) val[j] = mrz_g_loadu(&g->res[lane + 64 * j]);
-            if (watch_rev) rv = mrz_g_loadu(&g->rev[lane]);
+            if (watch_rev) rv = mrz_g_loadu(&g->rev[my_col]);
             if (lane == 63) ready = mrz_g_loadu(&g->ready);
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -849,23 +875,23 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
         }
         PROF_ADD(MRZ_ST_F_WAIT);
         ST_ADD(MRZ_ST_FARMED, 1);
-        // fold: the stop of entry e is the lowest offset any of its stripes reported
+        // fold: the stop of a column is the lowest offset any of its stripes reported
         if (lane < MRZ_FARM_ENTRIES) B->farm_min[lane] = MRZ_FARM_NONE;
         MRZ_WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned long long off = val[j] & MRZ_FARM_PAYLOAD;
-            if (watch[j] && off != MRZ_FARM_NONE) atomicMin(&B->farm_min[ent[j]], off);
+            if (watch[j] && off != MRZ_FARM_NONE) atomicMin(&B->farm_min[colw[j]], off);
         }
         MRZ_WAVE_SYNC();
-        const unsigned long long m = lane < MRZ_FARM_ENTRIES ? B->farm_min[lane] : MRZ_FARM_NONE;
-        const bool mine = lane < nsx && ((pending >> lane) & 1);
+        const unsigned long long m = mine ? B->farm_min[my_col] : MRZ_FARM_NONE;
         const bool resolved = mine && m != MRZ_FARM_NONE;
         if (resolved) fwd = (int64_t)m;
         if (watch_rev) rev = (int64_t)(rv & MRZ_FARM_PAYLOAD);
         pending &= ~__ballot(resolved);
-        base += (int64_t)G * MRZ_FARM_SPW;
+        base += (int64_t)G * mult * MRZ_FARM_SPW;
         want_rev = false;
+        rounds++;
         PROF_ADD(MRZ_ST_F_FOLD);
     }
     *my_fwd = fwd;
