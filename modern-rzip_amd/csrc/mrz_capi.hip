@@ -76,6 +76,7 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_index);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_state);
+    if (ctx->h_pos) hipHostFree(ctx->h_pos);
     hipFree(ctx->d_tags);
     hipFree(ctx->d_bitmap);
     hipFree(ctx->d_events);
@@ -141,6 +142,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_index, &cap, 256); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tab, &cap, ctx->nslots); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_state, &cap, 1); }
+    if (!rc && hipHostMalloc((void **)&ctx->h_pos, 64) != hipSuccess) rc = MRZ_E_NOMEM;
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tags, &cap, MRZ_SEG_POSITIONS); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_bitmap, &cap, MRZ_SEG_POSITIONS / 16 + 64); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_totals, &cap, 1); }
@@ -243,6 +245,8 @@ extern "C" int mrz_crc32(mrz_ctx *ctx, const void *buf, int64_t n, int where, ui
     return MRZ_OK;
 }
 
+#define MRZ_SEG_AHEAD 4  // segment launches the host keeps queued ahead of the device
+
 struct mrz_evpair {
     hipEvent_t a, b;
     int kind;  // 0 tagscan, 1 sequencer, 2 encode, 3 crc
@@ -329,10 +333,27 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     STEP(mrz_launch_crc32(s, d_buf, n, ctx->d_crc_tables, ctx->d_crc_parts, ctx->d_crc_out));
     PROF_END();
 
+    // The host stays MRZ_SEG_AHEAD segments ahead of the device and looks at the matcher's position of the
+    // segment that has just finished: a segment that an emitted match has already covered completely (a stream
+    // that repeats itself: one match of gigabytes) needs no tag scan and no sequencer launch at all.
+    int64_t *h_pos = ctx->h_pos;  // pinned; written by the copies below
+    *h_pos = 0;
+    hipEvent_t seg_ev[MRZ_SEG_AHEAD];
+    int n_seg_ev = 0;
+    for (int k = 0; k < MRZ_SEG_AHEAD && herr == hipSuccess; k++) {
+        STEP(hipEventCreateWithFlags(&seg_ev[k], hipEventDisableTiming));
+        if (herr == hipSuccess) n_seg_ev++;
+    }
+    int64_t launched = 0;
     for (int64_t sg = 0; sg < nseg && herr == hipSuccess; sg++) {
         const int64_t seg_start = sg * MRZ_SEG_POSITIONS;
         int64_t seg_len = end + 1 - seg_start;
         if (seg_len > MRZ_SEG_POSITIONS) seg_len = MRZ_SEG_POSITIONS;
+        if (launched >= MRZ_SEG_AHEAD) {
+            STEP(hipEventSynchronize(seg_ev[launched % MRZ_SEG_AHEAD]));  // the launch MRZ_SEG_AHEAD back is done
+            // positions are only ever visited in order: the last candidate of this segment is seg_start + seg_len - 1
+            if (herr == hipSuccess && *(volatile int64_t *)h_pos >= seg_start + seg_len - 1) continue;
+        }
         PROF_BEGIN(0);
         STEP(mrz_launch_tagscan(s, d_buf, n, seg_start, seg_len, ctx->d_index, ctx->d_state, ctx->d_tags,
                                 ctx->d_bitmap));
@@ -341,7 +362,11 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
                                   ctx->d_state, seg_start, seg_len, ctx->d_gmailbox));
         PROF_END();
+        STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));
+        launched++;
     }
+    for (int k = 0; k < n_seg_ev; k++) hipEventDestroy(seg_ev[k]);
     STEP(hipMemcpyAsync(&hs, ctx->d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
     STEP(hipMemcpyAsync(&crc, ctx->d_crc_out, 4, hipMemcpyDeviceToHost, s));
     STEP(hipStreamSynchronize(s));
@@ -401,7 +426,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         }
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) ctx->timings.total_ms = ms;
-        ctx->timings.n_segments = (int32_t)nseg;
+        ctx->timings.n_segments = (int32_t)launched;  // segments covered by an emitted match are not launched
         hipEventDestroy(ev_begin);
         hipEventDestroy(ev_end);
         free(evs);

@@ -25,6 +25,7 @@ struct mrz_ctx {
     int64_t *d_index;
     mrz_slot *d_tab;
     mrz_seq_state *d_state;
+    int64_t *h_pos;  // pinned host word: the matcher's position after the latest finished segment
     int64_t *d_tags;
     uint16_t *d_bitmap;
     mrz_event *d_events;

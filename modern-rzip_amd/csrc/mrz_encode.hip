@@ -107,6 +107,28 @@ __global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_scan_kernel(int64_t *
     }
 }
 
+#define MRZ_ENC_OWN_RECORDS 4
+
+// record r of an item (nl literal records, then nm match records) that starts at offset o0 of stream 0
+__device__ __forceinline__ void mrz_put_record(uint8_t *__restrict__ s0, int64_t o0, int64_t r, int64_t nl, int64_t nm,
+                                               int64_t ll, int64_t ml, int64_t dist, int cb) {
+    if (r < nl) {
+        const int64_t piece = r == nl - 1 ? ll - r * 0xFFFF : 0xFFFF;
+        const int64_t o = o0 + r * 3;
+        s0[o] = 0;
+        s0[o + 1] = (uint8_t)piece;
+        s0[o + 2] = (uint8_t)(piece >> 8);
+    } else {
+        const int64_t k = r - nl;
+        const int64_t piece = k == nm - 1 ? ml - k * 0xFFFF : 0xFFFF;
+        const int64_t o = o0 + nl * 3 + k * (3 + cb);
+        s0[o] = 1;
+        s0[o + 1] = (uint8_t)piece;
+        s0[o + 2] = (uint8_t)(piece >> 8);
+        for (int j = 0; j < cb; j++) s0[o + 3 + j] = (uint8_t)((uint64_t)dist >> (8 * j));
+    }
+}
+
 // pass 3: records into stream 0, per-item stream-1 offsets, statistics
 __global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_write_kernel(const mrz_event *__restrict__ ev, int64_t E,
                                                                         int64_t n, int cb,
@@ -130,28 +152,36 @@ __global__ __launch_bounds__(MRZ_ENC_THREADS) void mrz_enc_write_kernel(const mr
     int64_t o0 = block_s0[blockIdx.x] + c0;
     const int64_t o1 = block_s1[blockIdx.x] + c1;
     if (live) lit_off[i] = o1;
-    int64_t nlit = 0, nmat = 0;
     if (!live) ll = ml = 0;
-    for (int64_t rest = ll; rest > 0;) {
-        const int64_t piece = rest > 0xFFFF ? 0xFFFF : rest;
-        s0[o0] = 0;
-        s0[o0 + 1] = (uint8_t)piece;
-        s0[o0 + 2] = (uint8_t)(piece >> 8);
-        o0 += 3;
-        rest -= piece;
-        nlit++;
-    }
+    // item i = nl literal records, then nm match records (put_literal / put_match split at 0xFFFF, :183,:217)
+    const int64_t nl = mrz_pieces(ll), nm = mrz_pieces(ml);
+    const int64_t nlit = nl, nmat = nm;
     const int64_t dist = mp - mo;
-    for (int64_t rest = ml; rest > 0;) {
-        const int64_t piece = rest > 0xFFFF ? 0xFFFF : rest;
-        s0[o0] = 1;
-        s0[o0 + 1] = (uint8_t)piece;
-        s0[o0 + 2] = (uint8_t)(piece >> 8);
-        for (int k = 0; k < cb; k++) s0[o0 + 3 + k] = (uint8_t)((uint64_t)dist >> (8 * k));
-        o0 += 3 + cb;
-        rest -= piece;
-        nmat++;
+    // the first few records by the owning thread; an item with more of them (a match of gigabytes has tens of
+    // thousands) is finished by the whole workgroup below
+    for (int64_t r = 0; r < nl + nm && r < MRZ_ENC_OWN_RECORDS; r++) mrz_put_record(s0, o0, r, nl, nm, ll, ml, dist, cb);
+    {
+        __shared__ int64_t sh_o0[MRZ_ENC_THREADS], sh_ll[MRZ_ENC_THREADS], sh_ml[MRZ_ENC_THREADS], sh_dist[MRZ_ENC_THREADS];
+        __shared__ int sh_any;
+        const int tid = threadIdx.x;
+        if (tid == 0) sh_any = 0;
+        __syncthreads();
+        sh_o0[tid] = o0;
+        sh_ll[tid] = ll;
+        sh_ml[tid] = (nl + nm > MRZ_ENC_OWN_RECORDS) ? ml : -1;  // -1: nothing left to do for this item
+        sh_dist[tid] = dist;
+        if (nl + nm > MRZ_ENC_OWN_RECORDS) sh_any = 1;
+        __syncthreads();
+        if (sh_any)
+            for (int t = 0; t < MRZ_ENC_THREADS; t++) {
+                const int64_t tml = sh_ml[t];
+                if (tml < 0) continue;
+                const int64_t tll = sh_ll[t], tnl = mrz_pieces(tll), tnm = mrz_pieces(tml);
+                for (int64_t r = MRZ_ENC_OWN_RECORDS + tid; r < tnl + tnm; r += MRZ_ENC_THREADS)
+                    mrz_put_record(s0, sh_o0[t], r, tnl, tnm, tll, tml, sh_dist[t], cb);
+            }
     }
+    o0 += nl * 3 + nm * (3 + cb);
     // statistics (st->stats.* at src/rzip.c:188-189,219-220): reduced over the wave first
     {
         int64_t v0 = nlit, v1 = nlit ? ll : 0, v2 = nmat, v3 = nmat ? ml : 0;

@@ -565,9 +565,13 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
         int64_t r = -1;
         {
             const int64_t off0 = base + (int64_t)s * mult * MRZ_FARM_SPW + (int64_t)wave * mult * MRZ_FARM_WAVE_BYTES;
-            for (int k = 0; k < mult && r < 0; k++)
-                r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf,
-                                                                      off0 + (int64_t)k * MRZ_FARM_WAVE_BYTES, lane);
+            if (mult >= 4) {  // bulk rounds: 8 KiB per step (16 loads of 16 B in flight per lane)
+                for (int k = 0; k < mult * MRZ_FARM_WAVE_BYTES && r < 0; k += 8192)
+                    r = mrz_wave_fwd_stripe_n<8>(buf, p0, op, maxf, off0 + k, lane);
+            } else
+                for (int k = 0; k < mult && r < 0; k++)
+                    r = mrz_wave_fwd_stripe_n<MRZ_FARM_WAVE_BYTES / 1024>(buf, p0, op, maxf,
+                                                                          off0 + (int64_t)k * MRZ_FARM_WAVE_BYTES, lane);
         }
         // the last wave to arrive publishes the workgroup's answer (no barrier)
         if (lane == 0) {
