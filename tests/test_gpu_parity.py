@@ -135,6 +135,20 @@ def test_farm_multi_round_matches(gpu_lib, oracle):
     assert want["stats"]["match_bytes"] > 3 * 600000
 
 
+def test_exact_repeat_is_one_giant_match(gpu_lib, oracle):
+    """A block followed by exact copies of itself (what the S2 stream does beyond 4 GiB, what duplicate tar
+    members do): the copies are ONE match of ~88 MiB -- bulk farm rounds (every helper, 64-128 KiB each), host
+    skipping of the segments the match covers, ~1400 0xFFFF pieces written by a whole workgroup."""
+    blk = _util.rep64k(128, seed=41)  # 8 MiB
+    data = blk * 12
+    want = _parity.check_chunk(gpu_lib, oracle, data)
+    assert want["stats"]["matches"] > 1300 and want["stats"]["match_bytes"] > 11 * len(blk) - 100000
+    with m.RzipContext(lib=gpu_lib, max_chunk=len(data)) as ctx:
+        ctx.set_profiling(True)
+        ctx.rzip_chunk(data, fetch=False)
+        assert ctx.timings().n_segments < 6  # 96 MiB = 6 segments of 16 Mi positions; most are never launched
+
+
 def test_multi_chunk_file(gpu_lib, oracle):
     data = _util.rep64k(96, seed=13)  # 6 MiB, chunks of 2 MiB+
     _parity.check_file(gpu_lib, oracle, data, ramsize=3 * (2 << 20) // 2 + 5000)
