@@ -48,7 +48,8 @@
 #endif
 
 #ifndef MRZ_SEQ_WAVES
-#define MRZ_SEQ_WAVES 8  // 512 threads: 256 VGPRs per lane, no spills in the batch engine
+#define MRZ_SEQ_WAVES 3  // leader, one stripe helper, scout.  Measured 8 -> 3: -6 % on the benchmark chunk (no VGPR
+                         // spills, a third fewer SGPR spills, lighter helper workgroups); 2 (no scout) is slower
 #endif
 #define MRZ_SEQ_THREADS (64 * MRZ_SEQ_WAVES)
 // wave 0 = leader, waves 1..MRZ_STRIPE_WAVES-1 = striping helpers, last wave = scout (prefetcher)
@@ -431,11 +432,11 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 // A look-up on repetitive input can find max_chain_len tag-equal entries that are ALL tens of
 // KiB long (every earlier copy of the same text): megabytes to compare for one candidate.  One
 // CU keeps only ~8 KiB of loads in flight (~20 GB/s on cold data), so the compares are spread
-// over the whole chip: the grid carries helper workgroups (one per CU: 512 threads x 256 VGPRs
+// over the whole chip: the grid carries helper workgroups (one per CU: MRZ_SEQ_WAVES waves x 256 VGPRs
 // fill a CU) that wait on a mailbox in device memory.  A round compares, for every pending
 // entry, G consecutive stripes: the pending entries are compacted into 2^c columns, helper
-// ticket w takes stripe w >> c of column w & (2^c - 1) (16 KiB, from the second round on
-// 64-128 KiB; 2 KiB per wave and step) and reports where the compare stops inside its stripe,
+// ticket w takes stripe w >> c of column w & (2^c - 1) (2 KiB per wave; from the second round on
+// 8-32 KiB per wave, 2-8 KiB per step) and reports where the compare stops inside its stripe,
 // or "equal throughout"; the row of helpers after the forward rows measures the backward
 // halves.  A single entry that is still equal after the first round gets all helpers.
 //
@@ -469,6 +470,9 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #define MRZ_FARM_SPW (MRZ_SEQ_WAVES * MRZ_FARM_WAVE_BYTES)  // bytes of each stream per helper and round
 #define MRZ_FARM_GMAX 255  // rows fit the 8-bit field of the job word
 #define MRZ_FARM_ROWS0 14  // forward rows of a first round
+#ifndef MRZ_FARM_BULK_MULT
+#define MRZ_FARM_BULK_MULT 16  // 2 KiB sub-stripes per wave from the third round on (32 KiB per wave)
+#endif
 #define MRZ_FARM_SHIFT 40
 #define MRZ_FARM_PAYLOAD ((1ull << MRZ_FARM_SHIFT) - 1)
 #define MRZ_FARM_NONE MRZ_FARM_PAYLOAD
@@ -561,7 +565,7 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
             continue;
         }
         const int64_t maxf = (int64_t)s_job[par][1], base = (int64_t)s_job[par][3];
-        // this helper's stripe: mult x 16 KiB, each wave mult x 2 KiB of it, 2 KiB at a time until a difference
+        // this helper's stripe: each wave mult x 2 KiB of it, 2 KiB (bulk rounds: 8 KiB) at a time until a difference
         int64_t r = -1;
         {
             const int64_t off0 = base + (int64_t)s * mult * MRZ_FARM_SPW + (int64_t)wave * mult * MRZ_FARM_WAVE_BYTES;
@@ -807,7 +811,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
     while (pending) {
         // The pending entries are compacted into the first `np` columns; helper ticket w works on column
         // w & (ncols - 1), stripe row w >> lgc.  Rows 0..G-1 go forward, row G backward (first round only).
-        // From the second round on every helper takes several 16 KiB sub-stripes: entries that are still equal
+        // From the second round on every wave takes several 2 KiB sub-stripes: entries that are still equal
         // are long, and a match of gigabytes (a stream that repeats itself exactly) should move at HBM speed.
         const int np = __popcll(pending);
         int lgc = 0;
@@ -815,9 +819,9 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
         const int ncols = 1 << lgc;
         int G = (*C.gnw >> lgc) - (want_rev ? 1 : 0);
         if (G > MRZ_FARM_GMAX) G = MRZ_FARM_GMAX;
-        // first round: most matches end within 224 KiB, and every extra helper is one more answer to wait for
+        // first round: most matches end within its reach, and every extra helper is one more answer to wait for
         if (rounds == 0 && G > MRZ_FARM_ROWS0) G = MRZ_FARM_ROWS0;
-        const int mult = rounds == 0 ? 1 : (rounds == 1 ? 4 : 8);
+        const int mult = rounds == 0 ? 1 : (rounds == 1 ? 4 : MRZ_FARM_BULK_MULT);
         const int nass = G << lgc;
         const int my_col = __popcll(pending & mrz_low_mask(lane));  // column of entry `lane` (if pending)
         const bool mine = lane < nsx && ((pending >> lane) & 1);
