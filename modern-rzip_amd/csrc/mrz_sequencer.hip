@@ -432,8 +432,8 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 // A look-up on repetitive input can find max_chain_len tag-equal entries that are ALL tens of
 // KiB long (every earlier copy of the same text): megabytes to compare for one candidate.  One
 // CU keeps only ~8 KiB of loads in flight (~20 GB/s on cold data), so the compares are spread
-// over the whole chip: the grid carries helper workgroups (one per CU: MRZ_SEQ_WAVES waves x 256 VGPRs
-// fill a CU) that wait on a mailbox in device memory.  A round compares, for every pending
+// over the whole chip: the grid carries helper workgroups (MRZ_SEQ_WAVES waves each, about one per CU)
+// that wait on a mailbox in device memory.  A round compares, for every pending
 // entry, G consecutive stripes: the pending entries are compacted into 2^c columns, helper
 // ticket w takes stripe w >> c of column w & (2^c - 1) (2 KiB per wave; from the second round on
 // 8-32 KiB per wave, 2-8 KiB per step) and reports where the compare stops inside its stripe,
