@@ -592,8 +592,12 @@ __device__ static void mrz_helper_wg(const uint8_t *__restrict__ buf, mrz_gmailb
 
 // ---- definitions shared by the batch engine and the cooperative path ---------------------
 #define MRZ_SMAX 16
+#ifndef MRZ_WALK_SLOTS
 #define MRZ_WALK_SLOTS 8   // slots (16 B each) a lane loads per walk step: one 128-B line when aligned
+#endif
+#ifndef MRZ_WALK_STEPS
 #define MRZ_WALK_STEPS 12
+#endif
 #ifndef MRZ_WALK_LANE_STEPS
 #define MRZ_WALK_LANE_STEPS 2   // per-lane steps before long chains may be finished cooperatively
 #endif
