@@ -45,6 +45,25 @@ void mrz_free(void *p);
  * src/stream.c:797-914 for -n): returns max_chunk, *stream_bufsize optional */
 int64_t mrz_plan(const mrz_control *control, int64_t st_size, int64_t *stream_bufsize);
 
+/* ---- back-end hand-off ------------------------------------------------
+ * What the reference's sink does between rzip and the back-end codecs: every stream buffer that fills
+ * (stream_bufsize bytes, src/stream.c:878-914) is handed over as one block (flush_buffer :1307-1349 ->
+ * compthread :1115-1305) and the output keeps flush order.  mrz_rzip_pipeline runs the GPU rzip stage
+ * over the chunks of `in` and calls `fn` once per block, in that order, on a consumer thread that
+ * overlaps the GPU work on the next chunk; `fn` is where a back-end would compress (and frame) the block.
+ * A non-zero return of `fn` aborts the run and is returned. */
+typedef struct {
+    int chunk_index;      /* 0, 1, ... */
+    int stream;           /* 0 = control records, 1 = literal bytes */
+    int chunk_bytes;      /* width of the header fields of this chunk's blocks (src/rzip.c:1006-1008) */
+    int eof;              /* this is the file's last chunk (src/rzip.c:1049) */
+    int64_t chunk_size;
+    int first_of_chunk;   /* first block of the chunk: the chunk header precedes it in the file */
+} mrz_block_info;
+typedef int (*mrz_block_fn)(void *user, const mrz_block_info *info, const uint8_t *payload, int64_t len);
+int mrz_rzip_pipeline(const mrz_control *control, const void *in, int64_t n, mrz_block_fn fn, void *user,
+                      mrz_stats *stats, uint8_t *md5_out);
+
 /* `mrzip -d` of a whole -n archive held in memory: runzip_fd (src/runzip.c:332-437) over
  * runzip_chunk (:226-330), the block chains of the two streams (fill_buffer, src/stream.c:1412-1571;
  * CTYPE_NONE blocks only -- anything a back-end codec wrote gives MRZ_E_UNSUPPORTED) and the final

@@ -19,11 +19,12 @@ from .binding import (  # noqa: F401
     chunk_bytes,
     rzip_buffer,
     runzip_buffer,
+    rzip_pipeline,
     MEM_HOST,
     MEM_DEVICE,
 )
 
 __all__ = [
     "MrzError", "RzipContext", "ChunkResult", "Stats", "Timings", "Control", "lib_path", "load_library",
-    "chunk_bytes", "rzip_buffer", "runzip_buffer", "MEM_HOST", "MEM_DEVICE",
+    "chunk_bytes", "rzip_buffer", "runzip_buffer", "rzip_pipeline", "MEM_HOST", "MEM_DEVICE",
 ]

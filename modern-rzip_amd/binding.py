@@ -41,6 +41,16 @@ class Control(ctypes.Structure):
                 ("page_size", ctypes.c_int64), ("hash_code", ctypes.c_int), ("device", ctypes.c_int)]
 
 
+class BlockInfo(ctypes.Structure):
+    """mrz_block_info (include/mrzgpu_host.h)."""
+    _fields_ = [("chunk_index", ctypes.c_int), ("stream", ctypes.c_int), ("chunk_bytes", ctypes.c_int),
+                ("eof", ctypes.c_int), ("chunk_size", ctypes.c_int64), ("first_of_chunk", ctypes.c_int)]
+
+
+BLOCK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockInfo), ctypes.POINTER(ctypes.c_uint8),
+                            ctypes.c_int64)
+
+
 def lib_path():
     return os.environ.get("MRZGPU_LIB", os.path.join(_HERE, "libmrzgpu.so"))
 
@@ -103,6 +113,8 @@ def load_library(path=None):
         lib.mrz_runzip_chunk.argtypes = [vp, vp, i64, vp, i64, ci, ci, vp, ci, i64, ctypes.POINTER(i64), u32p, u32p]
     if hasattr(lib, "mrz_runzip_buffer"):
         lib.mrz_runzip_buffer.argtypes = [ci, vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    if hasattr(lib, "mrz_rzip_pipeline"):
+        lib.mrz_rzip_pipeline.argtypes = [ctypes.POINTER(Control), vp, i64, BLOCK_FN, vp, ctypes.POINTER(Stats), vp]
     if hasattr(lib, "mrz_rzip_buffer"):
         lib.mrz_rzip_buffer.argtypes = [ctypes.POINTER(Control), vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                         ctypes.POINTER(Stats), vp]
@@ -325,3 +337,25 @@ def runzip_buffer(mrz, device=0, lib=None):
         return ctypes.string_at(out, out_len.value)
     finally:
         lib.mrz_free(out)
+
+
+def rzip_pipeline(data, on_block, level=7, window=0, unlimited=False, ramsize=60 << 30, device=0, lib=None):
+    """mrz_rzip_pipeline: the GPU rzip stage over the chunks of `data`; `on_block(info_dict, payload_bytes)` is
+    called once per stream block in the reference's flush order (return None/0 to go on).  Returns (Stats, md5)."""
+    lib = lib or load_library()
+    ctl = Control(level, level, window, 1 if unlimited else 0, ramsize, 4096, 1, device)
+    ptr, n, where, keep = _as_ptr(data)
+    if where != MEM_HOST:
+        raise MrzError("rzip_pipeline takes host memory")
+
+    def trampoline(user, info, payload, length):
+        i = info.contents
+        d = dict(chunk_index=i.chunk_index, stream=i.stream, chunk_bytes=i.chunk_bytes, eof=i.eof,
+                 chunk_size=i.chunk_size, first_of_chunk=i.first_of_chunk)
+        return int(on_block(d, ctypes.string_at(payload, length)) or 0)
+
+    fn = BLOCK_FN(trampoline)
+    st = Stats()
+    md5 = ctypes.create_string_buffer(16)
+    _check(lib, lib.mrz_rzip_pipeline(ctypes.byref(ctl), ptr, n, fn, None, ctypes.byref(st), md5))
+    return st, md5.raw

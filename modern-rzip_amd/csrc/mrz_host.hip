@@ -7,6 +7,9 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -108,6 +111,37 @@ int64_t page_ceil(int64_t v, int64_t page) {  // round_up_page, src/util.c:171-1
     return r ? v + page - r : v;
 }
 
+// Replays a chunk's records into a two-stream writer so that "buffer full" events of the two streams
+// interleave as in the reference: the stream-1 bytes of a literal follow its 3-byte header (put_literal,
+// src/rzip.c:213-227).  W::write(stream, bytes, n).
+template <class W>
+int mrz_replay_records(W &w, int cb, const uint8_t *s0, int64_t n0, const uint8_t *s1, int64_t n1) {
+    int64_t i = 0, j = 0;
+    while (i < n0) {
+        if (i + 3 > n0) return MRZ_E_STATE;
+        const int head = s0[i];
+        const int64_t len = s0[i + 1] | (int64_t)s0[i + 2] << 8;
+        if (head == 0) {
+            w.write(0, s0 + i, 3);
+            i += 3;
+            if (len == 0) {
+                if (i + 4 != n0) return MRZ_E_STATE;
+                w.write(0, s0 + i, 4);
+                i += 4;
+                break;
+            }
+            if (j + len > n1) return MRZ_E_STATE;
+            w.write(1, s1 + j, len);
+            j += len;
+        } else {
+            if (i + 3 + cb > n0) return MRZ_E_STATE;
+            w.write(0, s0 + i, 3 + cb);
+            i += 3 + cb;
+        }
+    }
+    return j == n1 ? MRZ_OK : MRZ_E_STATE;
+}
+
 // ---- the -n stream sink ----------------------------------------------------
 // Two logical streams are cut into blocks whenever a stream buffer of
 // `bufsize` bytes fills (write_stream / flush_buffer), blocks are appended to
@@ -177,34 +211,9 @@ struct Sink {
             if ((int64_t)sbuf[s].size() == bufsize) emit_block(s);
         }
     }
-    // Replays the chunk's records so "buffer full" events of the two streams
-    // interleave as in the reference: the stream-1 bytes of a literal follow
-    // its 3-byte header (put_literal, src/rzip.c:213-227).
     int feed(const uint8_t *s0, int64_t n0, const uint8_t *s1, int64_t n1) {
-        int64_t i = 0, j = 0;
-        while (i < n0) {
-            if (i + 3 > n0) return MRZ_E_STATE;
-            const int head = s0[i];
-            const int64_t len = s0[i + 1] | (int64_t)s0[i + 2] << 8;
-            if (head == 0) {
-                write(0, s0 + i, 3);
-                i += 3;
-                if (len == 0) {
-                    if (i + 4 != n0) return MRZ_E_STATE;
-                    write(0, s0 + i, 4);
-                    i += 4;
-                    break;
-                }
-                if (j + len > n1) return MRZ_E_STATE;
-                write(1, s1 + j, len);
-                j += len;
-            } else {
-                if (i + 3 + cb > n0) return MRZ_E_STATE;
-                write(0, s0 + i, 3 + cb);
-                i += 3 + cb;
-            }
-        }
-        if (j != n1) return MRZ_E_STATE;
+        const int rc = mrz_replay_records(*this, cb, s0, n0, s1, n1);
+        if (rc) return rc;
         emit_block(0);  // close_stream_out flushes both, even when empty
         emit_block(1);
         return MRZ_OK;
@@ -350,6 +359,159 @@ extern "C" int mrz_rzip_fd(const mrz_control *ctl, int fd_in, int fd_out, mrz_st
         }
         off += (size_t)w;
     }
+    return MRZ_OK;
+}
+
+// ---- back-end hand-off pipeline -------------------------------------------------
+// The reference hands every full stream buffer to a compthread and keeps the output in flush order
+// (flush_buffer src/stream.c:1307-1349, compthread :1115-1305, the output_thread ticket :1199-1201).  Here the
+// GPU thread produces the two streams of chunk k+1 while a consumer thread cuts chunk k into blocks of
+// stream_bufsize bytes and hands them, in exactly that flush order, to the caller's function -- the place
+// where a back-end codec would compress the block.
+namespace {
+
+struct ChunkJob {
+    int index, cb, eof;
+    int64_t chunk_size;
+    std::vector<uint8_t> s0, s1;
+};
+
+struct BlockCutter {  // write_stream / flush_buffer without the file: every full buffer is one callback
+    mrz_block_fn fn;
+    void *user;
+    int64_t bufsize;
+    mrz_block_info info;
+    std::vector<uint8_t> sbuf[2];
+    int rc = 0;
+    void flush(int s) {
+        if (rc) return;
+        info.stream = s;
+        rc = fn(user, &info, sbuf[s].data(), (int64_t)sbuf[s].size());
+        info.first_of_chunk = 0;
+        sbuf[s].clear();
+    }
+    void write(int s, const uint8_t *p, int64_t n) {
+        while (n) {
+            const int64_t room = bufsize - (int64_t)sbuf[s].size();
+            const int64_t take = room < n ? room : n;
+            sbuf[s].insert(sbuf[s].end(), p, p + take);
+            p += take;
+            n -= take;
+            if ((int64_t)sbuf[s].size() == bufsize) flush(s);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int mrz_rzip_pipeline(const mrz_control *ctl, const void *in_v, int64_t n, mrz_block_fn fn, void *user,
+                                 mrz_stats *stats, uint8_t *md5_out) {
+    if (!ctl || !fn || n < 0 || (n > 0 && !in_v)) return MRZ_E_ARG;
+    if (ctl->rzip_compression_level < 1 || ctl->rzip_compression_level > 9) return MRZ_E_ARG;
+    const uint8_t *in = (const uint8_t *)in_v;
+    int64_t bufsize = 0;
+    const int64_t max_chunk = mrz_plan(ctl, n, &bufsize);
+
+    uint8_t md5[16];
+    std::thread hasher([&]() {  // whole-file hash beside everything else (src/rzip.c:1069-1090)
+        Md5 h;
+        h.update(in, (size_t)n);
+        h.finish(md5);
+    });
+
+    // consumer: cuts finished chunks into blocks, in order, while the GPU works on the next chunk
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<ChunkJob *> queue;
+    bool producer_done = false;
+    int consumer_rc = 0;
+    std::thread consumer([&]() {
+        BlockCutter cut;
+        cut.fn = fn;
+        cut.user = user;
+        cut.bufsize = bufsize;
+        for (;;) {
+            ChunkJob *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !queue.empty() || producer_done; });
+                if (queue.empty()) break;
+                job = queue.front();
+                queue.pop_front();
+            }
+            cv.notify_all();
+            if (!consumer_rc) {
+                cut.info.chunk_index = job->index;
+                cut.info.chunk_bytes = job->cb;
+                cut.info.eof = job->eof;
+                cut.info.chunk_size = job->chunk_size;
+                cut.info.first_of_chunk = 1;
+                int rc = mrz_replay_records(cut, job->cb, job->s0.data(), (int64_t)job->s0.size(), job->s1.data(),
+                                            (int64_t)job->s1.size());
+                if (!rc) {
+                    cut.flush(0);  // close_stream_out flushes both streams, even when empty (src/stream.c:1623-1648)
+                    cut.flush(1);
+                    rc = cut.rc;
+                }
+                if (rc) consumer_rc = rc;
+            }
+            delete job;
+        }
+    });
+
+    mrz_ctx *ctx = nullptr;
+    int rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, max_chunk < n ? max_chunk : n);
+    mrz_stats total;
+    memset(&total, 0, sizeof(total));
+    int64_t victim_round = 0, left = n, pos = 0;
+    int pass = 0;
+    while (!rc && (!pass || left > 0)) {  // chunk loop, src/rzip.c:915-1061
+        const int64_t csz = max_chunk < left ? max_chunk : left;
+        const int cb = mrz_chunk_bytes(csz);
+        mrz_chunk_result res;
+        rc = mrz_rzip_chunk(ctx, in + pos, csz, MRZ_MEM_HOST, cb, &victim_round, &res);
+        if (rc) break;
+        ChunkJob *job = new ChunkJob;
+        job->index = pass;
+        job->cb = cb;
+        job->eof = csz == left;
+        job->chunk_size = csz;
+        job->s0.resize((size_t)res.s0_len);
+        job->s1.resize((size_t)res.s1_len);
+        rc = mrz_fetch_streams(ctx, job->s0.data(), job->s1.data());
+        if (rc) {
+            delete job;
+            break;
+        }
+        total.inserts += res.stats.inserts;
+        total.literals += res.stats.literals;
+        total.literal_bytes += res.stats.literal_bytes;
+        total.matches += res.stats.matches;
+        total.match_bytes += res.stats.match_bytes;
+        total.tag_hits += res.stats.tag_hits;
+        total.tag_misses += res.stats.tag_misses;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return queue.size() < 2; });  // at most two finished chunks wait for the back-end
+            queue.push_back(job);
+        }
+        cv.notify_all();
+        pos += csz;
+        left -= csz;
+        pass++;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        producer_done = true;
+    }
+    cv.notify_all();
+    consumer.join();
+    hasher.join();
+    if (ctx) mrz_close(ctx);
+    if (!rc) rc = consumer_rc;
+    if (rc) return rc;
+    if (stats) *stats = total;
+    if (md5_out) memcpy(md5_out, md5, 16);
     return MRZ_OK;
 }
 

@@ -45,3 +45,49 @@ def check_file(lib, oracle, data, level=7, **kw):
     assert rc == 0 and back == data
     assert m.runzip_buffer(want, lib=lib) == data  # mrzip -d of the ORACLE's archive through the GPU decoder
     return got
+
+
+def _blocks_of_archive(mrz):
+    """(stream, payload) of every block of a -n archive in FILE order = the reference's flush order
+    (src/stream.c:1199-1293): walks the chunks, finds every block header by following both chains."""
+    out = []
+    at = 20 + mrz[19]
+    while True:
+        cb, eof = mrz[at], mrz[at + 1]
+        at += 2 + cb
+        initial = at
+        heads = {}  # file position of a block header -> stream
+        end_max = initial + 2 * (1 + 3 * cb)
+        for s in (0, 1):
+            pos = initial + s * (1 + 3 * cb)
+            first = True
+            while True:
+                c_len = int.from_bytes(mrz[pos + 1:pos + 1 + cb], "little")
+                nxt = int.from_bytes(mrz[pos + 1 + 2 * cb:pos + 1 + 3 * cb], "little")
+                if not first:
+                    heads[pos] = s
+                    end_max = max(end_max, pos + 1 + 3 * cb + c_len)
+                first = False
+                if not nxt:
+                    break
+                pos = initial + nxt
+        for pos in sorted(heads):
+            c_len = int.from_bytes(mrz[pos + 1:pos + 1 + cb], "little")
+            out.append((heads[pos], mrz[pos + 1 + 3 * cb:pos + 1 + 3 * cb + c_len]))
+        at = end_max
+        if eof:
+            return out
+
+
+def check_pipeline(lib, oracle, data, level=7, **kw):
+    """mrz_rzip_pipeline hands over exactly the blocks of the reference-identical archive, in file order."""
+    want, wstats, wmd5 = oracle.compress(data, level=level, **kw)
+    got = []
+    st, md5 = m.rzip_pipeline(data, lambda info, payload: got.append((info, payload)) and None, level=level, lib=lib, **kw)
+    assert md5 == wmd5 and st.as_dict() == wstats
+    blocks = _blocks_of_archive(want)
+    assert [(i["stream"], p) for i, p in got] == blocks
+    chunks = sorted({i["chunk_index"] for i, _ in got})
+    assert chunks == list(range(len(chunks)))
+    assert [i["eof"] for i, _ in got if i["first_of_chunk"]] == [0] * (len(chunks) - 1) + [1]
+    return got

@@ -161,3 +161,14 @@ def test_stride_repeats(emu_lib, oracle):
     data = w.stride_stream(12, 4096, copy_bytes=1500)
     want = _parity.check_chunk(emu_lib, oracle, data)
     assert want["stats"]["matches"] >= 2
+
+
+def test_backend_handoff_pipeline(emu_lib, oracle):
+    # three chunks; blocks must come in the reference's flush order with its block sizes
+    data = _util.rep64k(10, seed=13, period=4096) + _util.zipf_text(9000, seed=2)
+    got = _parity.check_pipeline(emu_lib, oracle, data, ramsize=3 * 16384 // 2 + 3000)
+    assert max(i["chunk_index"] for i, _ in got) >= 2
+    _parity.check_pipeline(emu_lib, oracle, b"")
+    # a callback error aborts the run and comes back
+    with pytest.raises(m.MrzError):
+        m.rzip_pipeline(data, lambda info, payload: -6, lib=emu_lib, ramsize=3 * 16384 // 2 + 3000)

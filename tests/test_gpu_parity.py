@@ -149,6 +149,14 @@ def test_exact_repeat_is_one_giant_match(gpu_lib, oracle):
         assert ctx.timings().n_segments < 6  # 96 MiB = 6 segments of 16 Mi positions; most are never launched
 
 
+def test_backend_handoff_pipeline(gpu_lib, oracle):
+    """mrz_rzip_pipeline: blocks of stream_bufsize bytes in the reference's flush order, several per stream
+    (24 MiB of literals against a 10 MiB buffer) and several chunks, GPU work overlapping the consumer."""
+    _parity.check_pipeline(gpu_lib, oracle, _util.xorshift_noise(24 << 20, seed=17) + _util.rep64k(40, seed=3))
+    got = _parity.check_pipeline(gpu_lib, oracle, _util.rep64k(96, seed=13), ramsize=3 << 20)
+    assert max(i["chunk_index"] for i, _ in got) >= 2
+
+
 def test_multi_chunk_file(gpu_lib, oracle):
     data = _util.rep64k(96, seed=13)  # 6 MiB, chunks of 2 MiB+
     _parity.check_file(gpu_lib, oracle, data, ramsize=3 * (2 << 20) // 2 + 5000)
