@@ -134,7 +134,9 @@ __device__ __forceinline__ void mrz_mb_add(int *p, int v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+#ifndef MRZ_STRIPE_PIECES
 #define MRZ_STRIPE_PIECES 4
+#endif
 #define MRZ_STRIPE (MRZ_STRIPE_PIECES * 1024)
 
 // Forward compare of one 4 KiB stripe starting at `base` (64 lanes x 16 B x 4
@@ -454,7 +456,11 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #ifndef MRZ_HELPER_WGS
 #define MRZ_HELPER_WGS 240  // most of the 256 CUs; the launcher may ask for fewer
 #endif
+#ifndef MRZ_HELPERS_PER_CU
+#define MRZ_HELPERS_PER_CU 1
+#endif
 #define MRZ_FARM_ENTRIES 16
+#define MRZ_FARM_WATCH ((MRZ_HELPER_WGS + 63) / 64)  // result words a leader lane watches
 #ifndef MRZ_FARM_WAVE_BYTES
 #define MRZ_FARM_WAVE_BYTES 2048
 #endif
@@ -469,7 +475,9 @@ __device__ static void mrz_helper_loop(const uint8_t *__restrict__ buf, mrz_mail
 #endif
 #define MRZ_FARM_SPW (MRZ_SEQ_WAVES * MRZ_FARM_WAVE_BYTES)  // bytes of each stream per helper and round
 #define MRZ_FARM_GMAX 255  // rows fit the 8-bit field of the job word
+#ifndef MRZ_FARM_ROWS0
 #define MRZ_FARM_ROWS0 14  // forward rows of a first round
+#endif
 #ifndef MRZ_FARM_BULK_MULT
 #define MRZ_FARM_BULK_MULT 16  // 2 KiB sub-stripes per wave from the third round on (32 KiB per wave)
 #endif
@@ -849,26 +857,28 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
         }
         PROF_ADD(MRZ_ST_F_POST);
         // which result words this lane watches
-        int colw[4];
-        bool watch[4];
+        int colw[MRZ_FARM_WATCH];
+        bool watch[MRZ_FARM_WATCH];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < MRZ_FARM_WATCH; j++) {
             const int w = lane + 64 * j;
             colw[j] = w & (ncols - 1);
             watch[j] = w < nass && colw[j] < np;
         }
         const bool watch_rev = want_rev && mine;
-        unsigned long long val[4] = { 0, 0, 0, 0 }, rv = 0, ready = 0;
+        unsigned long long val[MRZ_FARM_WATCH], rv = 0, ready = 0;
+#pragma unroll
+        for (int j = 0; j < MRZ_FARM_WATCH; j++) val[j] = 0;
         int spins = 0;
         while (true) {
             bool ok = true;
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < MRZ_FARM_WATCH; j++)
                 if (watch[j]) val[j] = mrz_g_loadu(&g->res[lane + 64 * j]);
             if (watch_rev) rv = mrz_g_loadu(&g->rev[my_col]);
             if (lane == 63) ready = mrz_g_loadu(&g->ready);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < MRZ_FARM_WATCH; j++)
                 if (watch[j]) ok = ok && (val[j] >> MRZ_FARM_SHIFT) == seq;
             if (watch_rev) ok = ok && (rv >> MRZ_FARM_SHIFT) == seq;
             if (__ballot(!ok) == 0) break;
@@ -891,7 +901,7 @@ __device__ static bool mrz_farm(const mrz_cfg &C, mrz_batch_lds *B, int64_t p0, 
         if (lane < MRZ_FARM_ENTRIES) B->farm_min[lane] = MRZ_FARM_NONE;
         MRZ_WAVE_SYNC();
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < MRZ_FARM_WATCH; j++) {
             const unsigned long long off = val[j] & MRZ_FARM_PAYLOAD;
             if (watch[j] && off != MRZ_FARM_NONE) atomicMin(&B->farm_min[colw[j]], off);
         }
@@ -2016,7 +2026,7 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
         int cus = 0, dev = 0;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        n_helpers = cus > 16 ? cus - 16 : 0;  // the leader's CU and a few for co-resident kernels stay free
+        n_helpers = cus > 16 ? (cus - 16) * MRZ_HELPERS_PER_CU : 0;  // the leader's CU and a few for co-resident kernels stay free
         const char *e = getenv("MRZ_FARM_WGS");
         if (e) n_helpers = atoi(e);
         if (n_helpers > MRZ_HELPER_WGS) n_helpers = MRZ_HELPER_WGS;
