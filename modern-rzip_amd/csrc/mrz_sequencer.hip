@@ -59,6 +59,15 @@
 #ifndef MRZ_SEQ_CREDIT
 #define MRZ_SEQ_CREDIT 8       // candidates sent through the cooperative path after repeated tiny batches
 #endif
+#ifndef MRZ_WIDTH_MULT
+#define MRZ_WIDTH_MULT 2
+#endif
+#ifndef MRZ_WIDTH_DENSE
+#define MRZ_WIDTH_DENSE 12
+#endif
+#ifndef MRZ_WIDTH_MULT_DENSE
+#define MRZ_WIDTH_MULT_DENSE 8
+#endif
 #ifndef MRZ_LOW_YIELD_RUNS
 #define MRZ_LOW_YIELD_RUNS 2
 #endif
@@ -1942,7 +1951,8 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             if (used >= width)
                 width = width * 2 > 64 ? 64 : width * 2;
             else {
-                const int want = 2 * used + 4;
+                // dense stretches (many lanes committed) regrow fast: a conflict cut there says little about the next batch
+                const int want = (used >= MRZ_WIDTH_DENSE ? MRZ_WIDTH_MULT_DENSE : MRZ_WIDTH_MULT) * used + 4;
                 width = want < 8 ? 8 : (want > 64 ? 64 : want);
             }
             if (used <= 2) {
