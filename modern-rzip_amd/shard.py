@@ -75,3 +75,75 @@ def rzip_file_chunk_chain(data, max_chunk, rank, world, rzip_chunk, dist=None):
     for part in gathered:
         merged.update(part)
     return [merged[k] for k in range(len(chunks))]
+
+
+# ---- range-sharded front-end of ONE chunk (second row) ------------------------
+# What shards inside a single window is everything except the sequencer: tag scan, CRC and literal gather work
+# on contiguous byte ranges (31-byte halo for the tags).  The pieces below are the host-side glue that is
+# independent of the transport: the byte ranges, and the combination of per-range CRC-32 values into the
+# chunk's CRC (src/rzip.c:662) -- CRC is linear over GF(2), so crc(A || B) follows from crc(A), crc(B) and
+# len(B) without touching the bytes again (the GPU kernel does the same across its tiles).
+
+def byte_ranges(total, world):
+    """Contiguous, 4 KiB-aligned byte range of every rank: [(offset, size)] * world (sizes may be 0)."""
+    per = -(-total // world)
+    per = -(-per // 4096) * 4096
+    out = []
+    for r in range(world):
+        off = min(r * per, total)
+        out.append((off, min(per, total - off)))
+    return out
+
+
+def _gf2_times(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def _gf2_square(mat):
+    return [_gf2_times(mat, mat[i]) for i in range(32)]
+
+
+def crc32_combine(crc_a, crc_b, len_b):
+    """CRC-32 (IEEE, as zlib / libgcrypt GCRY_MD_CRC32) of A || B from crc(A), crc(B) and len(B)."""
+    if len_b <= 0:
+        return crc_a
+    odd = [0xEDB88320] + [1 << i for i in range(31)]  # operator for one zero BIT
+    even = _gf2_square(odd)                            # two bits
+    odd = _gf2_square(even)                            # four bits
+    n = len_b
+    while True:  # apply len_b zero BYTES to crc_a
+        even = _gf2_square(odd)
+        if n & 1:
+            crc_a = _gf2_times(even, crc_a)
+        n >>= 1
+        if not n:
+            break
+        odd = _gf2_square(even)
+        if n & 1:
+            crc_a = _gf2_times(odd, crc_a)
+        n >>= 1
+        if not n:
+            break
+    return crc_a ^ crc_b
+
+
+def chunk_crc_sharded(data, rank, world, crc32_of, dist=None):
+    """Every rank checksums its byte range with crc32_of(bytes) -> int; rank 0 returns the chunk's CRC-32."""
+    off, size = byte_ranges(len(data), world)[rank]
+    mine = (crc32_of(data[off:off + size]) & 0xFFFFFFFF, size)
+    parts = [mine]
+    if dist is not None and world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+    if rank != 0:
+        return None
+    crc = 0
+    for c, n in parts:
+        crc = crc32_combine(crc, c, n)
+    return crc

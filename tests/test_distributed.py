@@ -61,6 +61,14 @@ def _worker(rank, world, port, q):
             assert got == want
             rc, back = oracle.decompress(got)
             assert rc == 0 and back == data
+        # (3) one chunk, CRC of byte ranges combined on rank 0 (range-sharded front-end); the per-range CRC is the
+        # library's kernel
+        import zlib
+        big = _util.zipf_text(300000, seed=5) + _util.xorshift_noise(70001, seed=6)
+        with m.RzipContext(lib=lib) as c2:
+            crc = shard.chunk_crc_sharded(big, rank, world, c2.crc32, dist)
+        if rank == 0:
+            assert crc == zlib.crc32(big)
         q.put((rank, "ok"))
     except BaseException as e:  # surface the failure in the parent
         q.put((rank, repr(e)))
@@ -90,3 +98,19 @@ def test_chunk_splitting_rules():
     assert shard.split_chunks(8192, 4096) == [(0, 4096), (4096, 4096)]
     assert shard.split_chunks(9000, 4096) == [(0, 4096), (4096, 4096), (8192, 808)]
     assert shard.streams_of_rank(5, 1, 2) == [1, 3]
+
+
+def test_crc32_combine_and_ranges():
+    import random
+    import zlib
+    from modern_rzip_amd import shard
+    rng = random.Random(4)
+    for _ in range(50):
+        a = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 3000)))
+        b = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 3000)))
+        assert shard.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    for total, world in ((0, 2), (1, 8), (4096, 2), (100000, 3), (10 << 30, 8)):
+        r = shard.byte_ranges(total, world)
+        assert len(r) == world and sum(n for _, n in r) == total
+        assert all(o % 4096 == 0 or n == 0 for o, n in r)
+        assert all(r[i][0] + r[i][1] == r[i + 1][0] or r[i + 1][1] == 0 for i in range(world - 1))
