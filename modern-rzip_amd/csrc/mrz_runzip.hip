@@ -267,7 +267,8 @@ __global__ __launch_bounds__(MRZ_UZ_DEC_THREADS) void mrz_uz_decode_kernel(const
     const int64_t TO = (int64_t)1 << tshift;
     __shared__ long long s_tile, s_first, s_prefix;
     __shared__ int s_fail;
-    long long known = 0;  // every tile below this index is known to be complete
+    long long known = 0;  // every tile below this index is known to be complete (and acquired)
+    unsigned long long vmask = 0;  // bit i: tile known + i has been seen complete and acquired as well
     while (true) {
         if (threadIdx.x == 0) {
             const long long t = (long long)__hip_atomic_fetch_add(&hdr->next_tile, 1ull, __ATOMIC_RELAXED,
@@ -312,7 +313,14 @@ __global__ __launch_bounds__(MRZ_UZ_DEC_THREADS) void mrz_uz_decode_kernel(const
                 const int64_t h1 = span == len ? from + (x1 - o) : from + span;
                 if (h0 < T0) {
                     const long long need_hi = (long long)(((h1 < T0 ? h1 : T0) - 1) >> tshift);
-                    if (need_hi >= known) {
+                    const long long need_lo = (long long)(h0 >> tshift) > known ? (long long)(h0 >> tshift) : known;
+                    bool seen = need_hi < known;
+                    if (!seen && need_hi - known < 64) {
+                        const unsigned long long hi_bits = need_hi - known == 63 ? ~0ull : ((1ull << (need_hi - known + 1)) - 1ull);
+                        const unsigned long long needmask = hi_bits & ~((1ull << (need_lo - known)) - 1ull);
+                        seen = (vmask & needmask) == needmask;
+                    }
+                    if (!seen) {
                         if (threadIdx.x == 0) {
                             long long spins = 0;
                             // relaxed polls (an acquire load would invalidate the L2 on every iteration); one acquire
@@ -338,8 +346,12 @@ __global__ __launch_bounds__(MRZ_UZ_DEC_THREADS) void mrz_uz_decode_kernel(const
                             if (threadIdx.x == 0) hdr->error = 2;
                             return;
                         }
-                        // only what the prefix counter says is remembered; single flags are re-checked next time
-                        known = s_prefix;
+                        // remember the prefix and, in a 64-tile window above it, the single tiles just seen
+                        const long long p = s_prefix > known ? s_prefix : known;
+                        vmask = p - known >= 64 ? 0ull : vmask >> (p - known);
+                        known = p;
+                        for (long long qq = need_lo > known ? need_lo : known; qq <= need_hi && qq - known < 64; qq++)
+                            vmask |= 1ull << (qq - known);
                         unordered = false;
                     }
                 }
