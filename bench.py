@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed GPU decode of the result")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the "
+                    "multi-process path with several ranks on one GPU: ranks wrap around the visible devices)")
     args = ap.parse_args()
 
     import torch
@@ -87,9 +89,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank
+    if args.dist_backend != "nccl":
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    if world > 1:
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     nper = int(args.gib * GIB) // 65536
     n = nper * 65536
@@ -97,7 +106,7 @@ def main():
     torch.cuda.synchronize()
 
     lib = m.load_library()
-    ctx = m.RzipContext(level=args.level, max_chunk=n, device=local_rank, lib=lib)
+    ctx = m.RzipContext(level=args.level, max_chunk=n, device=dev_index, lib=lib)
     ctx.set_profiling(True)
 
     def barrier():
@@ -126,7 +135,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
