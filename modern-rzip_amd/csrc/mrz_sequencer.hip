@@ -24,18 +24,21 @@
 //     * clean_one_from_hash (:305-328): 64 slots per sweep step.
 //     * single_match_len (:372-397): every tag-equal entry of a step is extended by
 //       its own lane, 64 B each way, in one load round trip (most differ there);
-//   waves 1..W-1 ("helpers") wait on an LDS mailbox.  A candidate that runs
-//   past 128 bytes takes the long path: its forward extension is striped over
-//   all W waves (W x 4 KiB per round, every wave 64 lanes x 16 B x 4 pieces,
-//   ballot + ffs for the first mismatch) and the leader folds the per-wave
-//   results.  Candidates are folded in probe order, so ties resolve exactly as
-//   in the reference.
+//   wave 1 ("stripe helper") waits on an LDS mailbox: a lone entry that runs past
+//   the 64-byte reach is extended by both waves (4 KiB each per round, 64 lanes x
+//   16 B x 4 pieces, ballot + ffs for the first mismatch); the last wave ("scout")
+//   runs ahead of the leader and touches what it will need next.
+//   Most candidates do not go one at a time: the BATCH ENGINE (mrz_batch_step)
+//   processes up to 64 consecutive candidates, one lane each, speculatively against
+//   the table as it stands, and commits the prefix that provably equals the
+//   sequential result.  Tag-equal entries that are all long go to the COMPARE FARM:
+//   helper workgroups on the other CUs (this kernel's blocks 1..) behind a mailbox
+//   in device memory.  Both are described where they are defined.
 // Emitted matches go to an event list; record encoding, literal gathering and
 // the CRC are separate parallel kernels.
 //
-// Bound: latency (dependent 1 KiB probes into the table, which lives in this
-// XCD's L2 / the Infinity Cache) and this CU's L1/L2 bandwidth for the match
-// extension -- not HBM bandwidth.
+// Bound: latency -- one dependency chain of table probes, data probes and
+// cross-CU hand-offs; see DESIGN.md 4.2 for the measured split.
 #include "mrz_device.h"
 #include <stdlib.h>
 
