@@ -101,6 +101,13 @@ int mrz_last_hip_error(const mrz_ctx *ctx, const char **text);
 void *mrz_stream(const mrz_ctx *ctx);
 int mrz_synchronize(mrz_ctx *ctx);
 int mrz_set_profiling(mrz_ctx *ctx, int enable);
+/* Helper workgroups per sequencer launch (the compare farm; default: the GPU's CU count - 16, or the
+ * MRZ_FARM_WGS environment variable).  Several ctxs (or processes) sharing one GPU should split the CUs
+ * between them, e.g. 224 / number of streams; 0 = no helpers (everything on the sequencer's own CU);
+ * negative = back to the default.  Independent streams then overlap on the device: measured 3.1x aggregate
+ * for 4 streams.  (In one process this needs GPU_MAX_HW_QUEUES >= 2 x ctxs when the HIP runtime initialises;
+ * the library sets 16 at load time unless the variable is already set.) */
+int mrz_set_farm_helpers(mrz_ctx *ctx, int n);
 int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out);
 
 /* ---- the rzip stage ---------------------------------------------------- */

@@ -7,7 +7,13 @@ which in turn mirrors the reference's ``rzip_fd`` / ``lz4_compresses`` /
 ``blake2b_*`` interfaces.  There is no CPU fallback: using any operation
 without a loadable ``libmrzgpu.so`` and a HIP device raises.
 """
-from .binding import (  # noqa: F401
+import os as _os
+
+# several RzipContexts of one process only overlap on the GPU if the HIP runtime may open enough hardware queues;
+# it reads this when it initialises (see mrz_set_farm_helpers in include/mrzgpu.h)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from .binding import (  # noqa: E402,F401
     MrzError,
     RzipContext,
     ChunkResult,

@@ -86,6 +86,8 @@ def load_library(path=None):
     lib.mrz_stream.restype = vp
     lib.mrz_synchronize.argtypes = [vp]
     lib.mrz_set_profiling.argtypes = [vp, ci]
+    if hasattr(lib, "mrz_set_farm_helpers"):
+        lib.mrz_set_farm_helpers.argtypes = [vp, ci]
     lib.mrz_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.mrz_rzip_chunk.argtypes = [vp, vp, i64, ci, ci, ctypes.POINTER(i64), ctypes.POINTER(ChunkResult)]
     lib.mrz_fetch_streams.argtypes = [vp, vp, vp]
@@ -187,6 +189,9 @@ class RzipContext:
     @property
     def stream(self):
         return self.lib.mrz_stream(self.ctx)
+
+    def set_farm_helpers(self, n):
+        _check(self.lib, self.lib.mrz_set_farm_helpers(self.ctx, n), self.ctx)
 
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.mrz_set_profiling(self.ctx, 1 if on else 0), self.ctx)

@@ -119,6 +119,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         return MRZ_E_NODEVICE;
     }
     mrz_ctx *ctx = (mrz_ctx *)calloc(1, sizeof(mrz_ctx));
+    if (ctx) ctx->farm_helpers = -1;
     if (!ctx) return MRZ_E_NOMEM;
     ctx->device = device;
     ctx->level = level;
@@ -200,6 +201,16 @@ extern "C" int mrz_set_profiling(mrz_ctx *ctx, int enable) {
     ctx->profiling = enable ? 1 : 0;
     return MRZ_OK;
 }
+
+extern "C" int mrz_set_farm_helpers(mrz_ctx *ctx, int n) {
+    if (!ctx) return MRZ_E_ARG;
+    ctx->farm_helpers = n < 0 ? -1 : n;
+    return MRZ_OK;
+}
+
+// Several ctxs of one process only overlap on the device if the HIP runtime may open enough hardware queues
+// (every ctx has two streams); the runtime reads this once, when it initialises.  Harmless if already set.
+__attribute__((constructor)) static void mrz_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 extern "C" int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out) {
     if (!ctx || !out) return MRZ_E_ARG;
@@ -360,7 +371,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         PROF_END();
         PROF_BEGIN(1);
         STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                  ctx->d_state, seg_start, seg_len, ctx->d_gmailbox));
+                                  ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, ctx->farm_helpers));
         PROF_END();
         STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));

@@ -45,6 +45,7 @@ struct mrz_ctx {
     int64_t crc_parts_cap;
     uint32_t *d_crc_out;
     void *d_gmailbox;  // mailbox of the sequencer's helper workgroups
+    int farm_helpers;  // helper workgroups per sequencer launch; -1 = the library default
     void *d_rs_tables;  // Reed-Solomon tables (mrz_rs.hip)
     uint8_t *d_rs_out;
     int64_t rs_out_cap;

@@ -2020,7 +2020,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 
 extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
                                            const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
-                                           int64_t seg_start, int64_t seg_len, void *gmailbox) {
+                                           int64_t seg_start, int64_t seg_len, void *gmailbox, int want_helpers) {
     mrz_seq_args a;
     a.buf = buf;
     a.tab = tab;
@@ -2047,6 +2047,7 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     }
 #endif
     a.n_helpers = gmailbox ? n_helpers : 0;
+    if (want_helpers >= 0 && want_helpers < a.n_helpers) a.n_helpers = want_helpers;  // per-ctx setting (mrz_set_farm_helpers)
     if (gmailbox) {
         hipError_t e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
         if (e != hipSuccess) return e;

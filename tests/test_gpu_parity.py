@@ -157,6 +157,32 @@ def test_backend_handoff_pipeline(gpu_lib, oracle):
     assert max(i["chunk_index"] for i, _ in got) >= 2
 
 
+def test_concurrent_contexts(gpu_lib, oracle):
+    """Independent streams on one GPU at once: one ctx and host thread each, the helper workgroups split between
+    them (mrz_set_farm_helpers).  Every stream must come out exactly as it does alone."""
+    import threading
+    datas = [_util.rep64k(48, seed=61), _util.zipf_text(3 << 20, seed=62), _util.rep64k(20, seed=63, period=30000) * 3,
+             _util.xorshift_noise(2 << 20, seed=64)]
+    wants = [oracle.rzip_chunk(d) for d in datas]
+    ctxs = [m.RzipContext(lib=gpu_lib, max_chunk=len(d)) for d in datas]
+    got = [None] * len(datas)
+
+    def work(i):
+        ctxs[i].set_farm_helpers(224 // len(datas))
+        res, s0, s1 = ctxs[i].rzip_chunk(datas[i])
+        got[i] = (s0, s1, res.crc32, res.stats.as_dict())
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(datas))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.close()
+    for g, wnt in zip(got, wants):
+        assert g == (wnt["s0"], wnt["s1"], wnt["crc"], wnt["stats"])
+
+
 def test_multi_chunk_file(gpu_lib, oracle):
     data = _util.rep64k(96, seed=13)  # 6 MiB, chunks of 2 MiB+
     _parity.check_file(gpu_lib, oracle, data, ramsize=3 * (2 << 20) // 2 + 5000)

@@ -1,5 +1,5 @@
 """S independent rep64k streams on ONE GPU at once (one ctx + host thread each): aggregate GiB/s.
-usage: MRZ_FARM_WGS=<helpers per stream> python tools/probe_multistream.py S GIB_PER_STREAM"""
+usage: python tools/probe_multistream.py S GIB_PER_STREAM   (helpers are split 224 / S per stream)"""
 import sys, os, time, json, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,8 @@ nper = int(gib * (1 << 30)) // 65536
 n = nper * 65536
 data = [w.rep64k_device(nper, "cuda", seed=1234 + i) for i in range(S)]
 ctxs = [m.RzipContext(level=7, max_chunk=n) for _ in range(S)]
+for c in ctxs:
+    c.set_farm_helpers(224 // S)
 res = [None] * S
 def work(i):
     ctxs[i].victim_round = 0
