@@ -106,7 +106,7 @@ int mrz_set_profiling(mrz_ctx *ctx, int enable);
  * between them, e.g. 224 / number of streams; 0 = no helpers (everything on the sequencer's own CU);
  * negative = back to the default.  Independent streams then overlap on the device: measured 3.1x aggregate
  * for 4 streams.  (In one process this needs GPU_MAX_HW_QUEUES >= 2 x ctxs when the HIP runtime initialises;
- * the library sets 16 at load time unless the variable is already set.) */
+ * the library sets 8 at load time unless the variable is already set.) */
 int mrz_set_farm_helpers(mrz_ctx *ctx, int n);
 int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out);
 

@@ -11,7 +11,7 @@ import os as _os
 
 # several RzipContexts of one process only overlap on the GPU if the HIP runtime may open enough hardware queues;
 # it reads this when it initialises (see mrz_set_farm_helpers in include/mrzgpu.h)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .binding import (  # noqa: E402,F401
     MrzError,

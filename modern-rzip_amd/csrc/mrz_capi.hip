@@ -210,7 +210,7 @@ extern "C" int mrz_set_farm_helpers(mrz_ctx *ctx, int n) {
 
 // Several ctxs of one process only overlap on the device if the HIP runtime may open enough hardware queues
 // (every ctx has two streams); the runtime reads this once, when it initialises.  Harmless if already set.
-__attribute__((constructor)) static void mrz_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor)) static void mrz_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out) {
     if (!ctx || !out) return MRZ_E_ARG;
