@@ -119,8 +119,9 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         return MRZ_E_NODEVICE;
     }
     mrz_ctx *ctx = (mrz_ctx *)calloc(1, sizeof(mrz_ctx));
-    if (ctx) ctx->farm_helpers = -1;
     if (!ctx) return MRZ_E_NOMEM;
+    ctx->farm_helpers = -1;
+    ctx->farm_default = mrz_sequencer_default_helpers(device);
     ctx->device = device;
     ctx->level = level;
     ctx->mb_used = k_levels[level][0];
@@ -371,7 +372,9 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         PROF_END();
         PROF_BEGIN(1);
         STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                  ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, ctx->farm_helpers));
+                                  ctx->d_state, seg_start, seg_len, ctx->d_gmailbox,
+                                  ctx->farm_helpers >= 0 && ctx->farm_helpers < ctx->farm_default ? ctx->farm_helpers
+                                                                                                   : ctx->farm_default));
         PROF_END();
         STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));
@@ -471,12 +474,13 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->hash_count = hs.count;
     res->n_events = E;
     if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[40] = { "batches", "batch_lanes", "seq_cands", "cut_long", "cut_walk", "cut_conflict",
-                                         "cut_cull", "batch_emits", "cut_cascade", "pairs", "formed", "t_form", "t_walk",
-                                         "t_walk2", "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window", "t_long",
-                                         "t_fold", "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait", "f_fold",
-                                         "f_helper_max", "h_fields", "h_fwd", "h_bwd", "h_drain", "h_rounds", "s_tab", "s_pair", "s_ins" };
-        for (int k = 0; k < 40; k++) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
+        static const char *names[64] = { "batches", "formed", "committed", "segments", "emits", "backjump", "rewalk",
+                                         "longres", "seq_cands", "cut_cplx", "cut_overflow", "skipout", "conf0", "pairs",
+                                         "t_form", "t_walk", "t_conf", "t_pairs", "t_loop", "t_rewalk", "t_long", "t_seq",
+                                         "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
+                                         "f_fold", "s_tab", "s_pair", "s_ins", "ovl", "ovl_ok", "x_walk", "x_casc", "x_pool",
+                                         "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw" };
+        for (int k = 0; k < 64; k++) if (names[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

@@ -45,7 +45,7 @@ struct mrz_seq_state {
     int32_t finished;     // main loop has reached `end`
     int32_t error;        // nonzero: event list overflow etc.
     int64_t pad[8];
-    int64_t prof[40];     // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
+    int64_t prof[64];     // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
 };
 
 // result of the record-sizing pass

@@ -45,7 +45,8 @@ struct mrz_ctx {
     int64_t crc_parts_cap;
     uint32_t *d_crc_out;
     void *d_gmailbox;  // mailbox of the sequencer's helper workgroups
-    int farm_helpers;  // helper workgroups per sequencer launch; -1 = the library default
+    int farm_helpers;  // helper workgroups per sequencer launch; -1 = farm_default
+    int farm_default;  // the default for this ctx's device (about one per CU), fixed in mrz_open
     void *d_rs_tables;  // Reed-Solomon tables (mrz_rs.hip)
     uint8_t *d_rs_out;
     int64_t rs_out_cap;

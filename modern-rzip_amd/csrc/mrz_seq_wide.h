@@ -1,0 +1,1467 @@
+// mrz_seq_wide.h -- the WIDE BATCH ENGINE of the sequencer workgroup.
+//
+// hash_search's loop (src/rzip.c:548-599) must be replayed in order, but most of what a candidate costs is
+// read-only: the probe walk of find_best_match / insert_hash (:426-462, :262-297) and the byte compares of
+// single_match_len (:372-397).  A batch takes the next MRZ_W (= 64 x waves) candidates of the position stream,
+// ONE LANE PER CANDIDATE, and runs in phases, all waves of the workgroup together:
+//
+//   A  formation   the next candidates from the tag-scan bitmap (one 64-position word per thread, workgroup
+//                  prefix sum of the popcounts, rank -> position), their tags; the cull window: a bitmask of the
+//                  entries ahead of tag_clean_ptr that fail the next mask (clean_one_from_hash, :313-321);
+//   B  walk        every lane walks its probe chain in the table AS IT STANDS (8 slots = one 128-B line per step,
+//                  long chains are finished by the lane's whole wave, 64 slots per step): first empty slot, the
+//                  tag-equal entries in probe order, where insert_hash's walk stops (empty / due-for-culling
+//                  overwrite / lower-ranked occupant to displace / max_chain_len-th tag-equal entry => eviction)
+//                  and the walk of a displaced occupant;
+//   B2 conflicts   the slots a lane would write go into a hash of 64-slot blocks in LDS; a lane whose read
+//                  ranges hold a write of an EARLIER lane is marked stale.  A stale lane whose writers are all
+//                  sound walks once more with those writes laid over the table (overlay: the common case is the
+//                  next position having the same tag -- the XOR tag only sees the multiset of its 31 bytes);
+//   C  pairs       all (candidate, tag-equal entry) pairs are laid end to end and dealt one per thread: 64 bytes
+//                  each way, stored RAW (independent of last_match) so that they can be re-bounded later;
+//   E  commit      segments of lanes are committed in order.  A segment ends at the first lane that is stale,
+//                  needs the cooperative path, or has a match running past the 64-byte reach.  Within a segment
+//                  workgroup-wide scans give the sequential quantities: victim_round per evicting lane,
+//                  hash_count before each lane (saturating prefix sum), which lanes cull and which sweep entry
+//                  each culls (rank into the cull window), and the lazy-match fold (:586-599) as a prefix
+//                  maximum (first longest wins) whose first lane meeting the emit rule (:592) ends the segment.
+//                  After an emission the batch goes on behind the match (the lanes inside it are dropped); a
+//                  match that ends before the emitting position (p jumps BACK, :596) re-executes that one lane.
+//                  A stale lane at the head of a segment walks again against the table as committed so far.
+//
+// What is committed is exactly what the reference's loop would have done: a lane only commits if no earlier
+// lane's write (insert, displaced re-insert, cull) lies in the slots it read -- or it has read them again since.
+#pragma once
+#include "mrz_seq_common.h"
+
+#define MRZ_W MRZ_SEQ_THREADS
+#define MRZ_POOL 1024                 // chunks of 4 tag-equal entries
+#define MRZ_PAIR_MAX (MRZ_POOL * 4)
+#define MRZ_BH_SIZE 2048              // block-hash entries (64-slot blocks written by this batch)
+#define MRZ_BH_WRITERS 3
+#define MRZ_CW_WORDS 32               // cull window: 32 x 64 slots ahead of tag_clean_ptr
+#define MRZ_NW_MAX 192
+#define MRZ_OFF_BITS 40
+#define MRZ_OFF_MASK ((1ull << MRZ_OFF_BITS) - 1)
+
+struct mrz_chunk4 {
+    unsigned long long e[4];  // offset | slot << 40
+    unsigned short raw[4];    // fwd (7 bits) | fwd may continue << 7 | bwd (7 bits) << 8
+};
+
+struct mrz_wide_lds {
+    mrz_lead Lp;          // the leader's state, published by wave 0 before a wide step
+    int ctl[16];          // control words between wave 0 and the others
+    int64_t res64[4];     // long-match resolution of one lane: len, off, rev, (hits << 32 | misses)
+    // formation
+    int pref[MRZ_W];
+    mrz_u64 word[MRZ_W];
+    // per-lane facts other lanes / waves need
+    int64_t q[MRZ_W];
+    int h[MRZ_W], len1[MRZ_W], h2[MRZ_W], len2[MRZ_W], wslot[MRZ_W], w2[MRZ_W];
+    unsigned char kind[MRZ_W], kind2[MRZ_W], ns[MRZ_W], lf[MRZ_W], nchunk[MRZ_W];
+    int64_t t[MRZ_W], occ_off[MRZ_W], occ_t[MRZ_W];
+    unsigned short supp_w[MRZ_W], supp_w2[MRZ_W];  // first later lane that overwrites this lane's insert / occupant slot
+    int nw_cnt;                      // writes of overlay-walked lanes: slots other lanes have to re-check
+    int nw_slot[MRZ_NW_MAX];
+    unsigned short nw_lane[MRZ_NW_MAX];
+    int A1[MRZ_W];                 // inclusive scan: delta | evictions << 10 | inserts << 20
+    unsigned long long A2[MRZ_W];  // inclusive scan: culls | hits << 16 | misses << 32
+    unsigned long long fkey[MRZ_W];
+    int64_t boff[MRZ_W];
+    int brev[MRZ_W];
+    int pbase[MRZ_W];
+    unsigned short chunk_id[MRZ_W][4];
+    unsigned short pair_owner[MRZ_PAIR_MAX];
+    mrz_chunk4 pool[MRZ_POOL];
+    unsigned bh_key[MRZ_BH_SIZE];
+    unsigned bh_cnt[MRZ_BH_SIZE];
+    unsigned short bh_lane[MRZ_BH_SIZE][MRZ_BH_WRITERS];
+    mrz_u64 cw[MRZ_CW_WORDS];
+    int cwcum[MRZ_CW_WORDS + 1];
+    int wt1[MRZ_SEQ_WAVES], wt3[MRZ_SEQ_WAVES], wt5[MRZ_SEQ_WAVES];
+    unsigned long long wt2[MRZ_SEQ_WAVES], wt4[MRZ_SEQ_WAVES];
+    int wmin[4][MRZ_SEQ_WAVES];
+    int pool_top;
+    mrz_coop_lds coop;
+};
+
+enum { MRZ_CTL_MODE, MRZ_CTL_WIDTH, MRZ_CTL_STOPKIND, MRZ_CTL_OK, MRZ_CTL_LONGSEEN };
+
+// ---- workgroup-wide scans (all threads; one barrier each; `wt` must not be reused before another barrier) ----
+__device__ __forceinline__ int mrz_wide_incl(int v, int *wt, int lane, int wave, int *total) {
+    const int incl = mrz_wave_incl_sum(v, lane);
+    if (lane == 63) wt[wave] = incl;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MRZ_SEQ_WAVES; w++) {
+        const int x = wt[w];
+        tot += x;
+        if (w < wave) add += x;
+    }
+    *total = tot;
+    return incl + add;
+}
+
+__device__ __forceinline__ mrz_u64 mrz_wide_incl64(mrz_u64 v, unsigned long long *wt, int lane, int wave) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const mrz_u64 o = (mrz_u64)mrz_shfl64((int64_t)v, lane - d >= 0 ? lane - d : lane);
+        if (lane >= d) v += o;
+    }
+    if (lane == 63) wt[wave] = v;
+    __syncthreads();
+    mrz_u64 add = 0;
+#pragma unroll
+    for (int w = 0; w < MRZ_SEQ_WAVES; w++)
+        if (w < wave) add += wt[w];
+    return v + add;
+}
+
+__device__ __forceinline__ mrz_u64 mrz_wide_inclmax64(mrz_u64 v, unsigned long long *wt, int lane, int wave) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const mrz_u64 o = (mrz_u64)mrz_shfl64((int64_t)v, lane - d >= 0 ? lane - d : lane);
+        if (lane >= d && o > v) v = o;
+    }
+    if (lane == 63) wt[wave] = v;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < MRZ_SEQ_WAVES; w++)
+        if (w < wave && wt[w] > v) v = wt[w];
+    return v;
+}
+
+// first thread (lowest tid) for which `flag` holds, or `none`; up to 4 independent reductions share one barrier
+__device__ __forceinline__ int mrz_wave_first(bool flag, int wave, int none) {
+    const mrz_u64 m = __ballot(flag);
+    return m ? wave * 64 + (__ffsll((long long)m) - 1) : none;
+}
+__device__ __forceinline__ int mrz_wide_min_read(const int *wm) {
+    int r = wm[0];
+#pragma unroll
+    for (int w = 1; w < MRZ_SEQ_WAVES; w++) r = wm[w] < r ? wm[w] : r;
+    return r;
+}
+
+#ifdef MRZ_SEQ_STATS
+// diagnostics: number of threads of the workgroup for which `flag` holds (all threads call; one barrier)
+#define ST_COUNT(k, flag)                                                                           \
+    do {                                                                                            \
+        const mrz_u64 m__ = __ballot(flag);                                                         \
+        int t__;                                                                                    \
+        (void)mrz_wide_incl(lane == 0 ? __popcll(m__) : 0, S->wt5, lane, wave, &t__);               \
+        __syncthreads();                                                                            \
+        ST_ADD(k, t__);                                                                             \
+    } while (0)
+#else
+#define ST_COUNT(k, flag) ((void)0)
+#endif
+
+// ---- tag-equal entries of a lane: chunks of 4 out of a pool in LDS ----
+__device__ __forceinline__ bool mrz_pool_put(mrz_wide_lds *S, int gl, int idx, int64_t off, int slot) {
+    if ((idx & 3) == 0 && (idx >> 2) >= S->nchunk[gl]) {  // a lane that walks again keeps its chunks
+        const int c = atomicAdd(&S->pool_top, 1);
+        if (c >= MRZ_POOL) return false;
+        S->chunk_id[gl][idx >> 2] = (unsigned short)c;
+        S->nchunk[gl] = (unsigned char)((idx >> 2) + 1);
+    }
+    const int c = S->chunk_id[gl][idx >> 2];
+    S->pool[c].e[idx & 3] = (unsigned long long)off | ((unsigned long long)(unsigned)slot << MRZ_OFF_BITS);
+    return true;
+}
+__device__ __forceinline__ unsigned long long mrz_pool_get(const mrz_wide_lds *S, int gl, int idx) {
+    return S->pool[S->chunk_id[gl][idx >> 2]].e[idx & 3];
+}
+
+// raw 64-byte probe of one (candidate, entry) pair, independent of last_match (single_match_len,
+// src/rzip.c:372-397): bits 0-6 equal bytes forward (capped by end - q), bit 7 "forward runs past the reach",
+// bits 8-14 equal bytes backward among the 64 before (pieces that would start before byte 0 of the chunk count
+// as equal: mrz_pair_eval knows from `op` which ones those are)
+__device__ static unsigned mrz_lane_probe_raw(const uint8_t *__restrict__ buf, int64_t q, int64_t op, int64_t end) {
+    if (op >= q) return 0;
+    int64_t maxf = end - q;
+    if (maxf < 0) maxf = 0;
+    const int64_t last_ok = end + (MRZ_MIN_MATCH - 16);
+    uint4 fa[4], fb[4], ba[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int64_t pa = q + j * 16, pb = op + j * 16;
+        pa = pa < last_ok ? pa : last_ok;
+        pb = pb < last_ok ? pb : last_ok;
+        fa[j] = mrz_ld16(buf + pa);
+        fb[j] = mrz_ld16(buf + pb);
+        int64_t ra = q - (j + 1) * 16, rb = op - (j + 1) * 16;
+        ra = ra > 0 ? ra : 0;
+        rb = rb > 0 ? rb : 0;
+        ba[j] = mrz_ld16(buf + ra);
+        bb[j] = mrz_ld16(buf + rb);
+    }
+    int rawf;
+    {
+        const int d0 = mrz_first_diff16_bf(fa[0], fb[0]), d1 = mrz_first_diff16_bf(fa[1], fb[1]);
+        const int d2 = mrz_first_diff16_bf(fa[2], fb[2]), d3 = mrz_first_diff16_bf(fa[3], fb[3]);
+        rawf = d0 < 16 ? d0 : 16 + (d1 < 16 ? d1 : 16 + (d2 < 16 ? d2 : 16 + d3));
+    }
+    const int fwd = rawf < maxf ? rawf : (int)maxf;
+    const unsigned lngf = (rawf == 64 && maxf > 64) ? 1u : 0u;
+    const int edge = op < 64 ? (int)(op >> 4) : 4;
+    int rawb;
+    {
+        const int e0 = edge > 0 ? mrz_top_equal16_bf(ba[0], bb[0]) : 16, e1 = edge > 1 ? mrz_top_equal16_bf(ba[1], bb[1]) : 16;
+        const int e2 = edge > 2 ? mrz_top_equal16_bf(ba[2], bb[2]) : 16, e3 = edge > 3 ? mrz_top_equal16_bf(ba[3], bb[3]) : 16;
+        rawb = e0 < 16 ? e0 : 16 + (e1 < 16 ? e1 : 16 + (e2 < 16 ? e2 : 16 + e3));
+    }
+    return (unsigned)fwd | (lngf << 7) | ((unsigned)rawb << 8);
+}
+
+// single_match_len's result for a raw probe under the current last_match; *lng: the match runs past the reach
+__device__ __forceinline__ void mrz_pair_eval(unsigned raw, int64_t q, int64_t op, int64_t floor_p, int64_t *len,
+                                              int *rev, bool *lng) {
+    *len = 0;
+    *rev = 0;
+    *lng = false;
+    if (op >= q) return;
+    const int fwd = (int)(raw & 127u), rawb = (int)((raw >> 8) & 127u);
+    int64_t maxb = q - floor_p;
+    if (op < maxb) maxb = op;
+    if (maxb < 0) maxb = 0;
+    const int edge = op < 64 ? (int)(op >> 4) : 4;
+    const bool l = ((raw >> 7) & 1u) || (rawb == 64 && maxb > 64) || (edge < 4 && rawb >= 16 * edge && maxb > 16 * edge);
+    if (l) {
+        *lng = true;
+        return;
+    }
+    const int rv = rawb < maxb ? rawb : (int)maxb;
+    *rev = rv;
+    const int tot = fwd + rv;
+    *len = tot >= MRZ_MIN_MATCH ? tot : 0;
+}
+
+// ---- phase B: the probe walk of one lane (and of the occupant it displaces) -----------------------------
+struct mrz_ov {  // writes of earlier lanes laid over the table for an overlay walk
+    int n;
+    int slot[4];
+    int64_t off[4], t[4];
+};
+
+struct mrz_wl {
+    int fe, wslot, kind, nsame, h2, w2, kind2, len2;
+    bool cplx;
+    int why;  // first reason for cplx (diagnostics): 1 walk budget, 2 cascade, 3 pool, 4 too many tag-equal entries
+    int64_t occ_t, occ_off;
+};
+
+__device__ __forceinline__ mrz_slot mrz_tab_load(const mrz_slot *tab, int slot, const mrz_ov *ov) {
+    mrz_slot e = tab[slot];
+    if (ov) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < ov->n && ov->slot[k] == slot) {  // a later overlay entry wins (written later)
+                e.off = ov->off[k];
+                e.t = ov->t[k];
+            }
+    }
+    return e;
+}
+
+// `go`: this lane walks (the others only take part in the wave-cooperative finish of long chains).  `ov`: per-lane
+// overlay (nullptr-equivalent when ov.n == 0 and USE_OV is false).
+template <bool USE_OV>
+__device__ static void mrz_wide_walk(const mrz_cfg &C, mrz_wide_lds *S, bool go, int gl, int lane, int64_t t, bool do_ins,
+                                     int64_t better, const mrz_ov &ovl, mrz_wl &o) {
+    const mrz_slot *tab = C.tab;
+    const int smask = (int)C.slot_mask;
+    const int max_chain = (int)C.max_chain;
+    const int h = (int)(t & C.slot_mask);
+    const int my_rank = mrz_ones_rank(t);
+    const mrz_ov *ov = USE_OV ? &ovl : nullptr;
+    int fe = -1, wslot = -1, kind = -1;  // kind: 0 empty, 1 overwrite, 2 displace, 3 evict
+    int nsame = 0, round = 0;
+    bool cplx = false, evict = false;
+    int why = 0;
+    int64_t occ_t = 0, occ_off = 0;
+    const int gl0 = gl - lane;  // first lane of this wave
+#define MRZ_CPLX(code)         \
+    do {                       \
+        cplx = true;           \
+        if (!why) why = (code); \
+    } while (0)
+    {
+        bool walking = go;
+        int s = h, steps = 0;
+        int ustep = 0;
+        while (true) {
+            const mrz_u64 m_walk = __ballot(walking);
+            if (!m_walk) break;
+            if (ustep >= MRZ_WALK_LANE_STEPS && __popcll(m_walk) <= MRZ_WALK_COOP_MAX) break;
+            ustep++;
+            if (walking) {
+                mrz_slot e[MRZ_WALK_SLOTS];
+#pragma unroll
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) e[k] = mrz_tab_load(tab, (s + k) & smask, ov);
+#pragma unroll
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) {
+                    if (!walking) continue;
+                    const int slot = (s + k) & smask;
+                    if ((e[k].off | e[k].t) == 0) {
+                        fe = slot;
+                        if (do_ins && wslot < 0 && !evict) {
+                            wslot = slot;
+                            kind = 0;
+                        }
+                        walking = false;
+                        continue;
+                    }
+                    if (do_ins && wslot < 0 && !evict) {
+                        if ((e[k].t & better) != better) {
+                            wslot = slot;
+                            kind = 1;
+                        } else if (mrz_ones_rank(e[k].t) < my_rank) {
+                            wslot = slot;
+                            kind = 2;
+                            occ_t = e[k].t;
+                            occ_off = e[k].off;
+                        } else if (e[k].t == t) {
+                            if (++round == max_chain) {
+                                evict = true;
+                                kind = 3;
+                            }
+                        }
+                    }
+                    if (e[k].t == t) {
+                        if (nsame < MRZ_SMAX) {
+                            if (!mrz_pool_put(S, gl, nsame, e[k].off, slot)) MRZ_CPLX(3);
+                        } else
+                            MRZ_CPLX(4);
+                        nsame++;
+                    }
+                }
+                s += MRZ_WALK_SLOTS;
+                if (walking && ++steps >= MRZ_WALK_STEPS) {
+                    MRZ_CPLX(1);
+                    walking = false;
+                }
+            }
+        }
+        // stragglers: the rest of a long chain, the whole wave on one lane's chain (64 slots per step)
+        for (mrz_u64 todo = __ballot(walking); todo; todo &= todo - 1) {
+            const int ol = __ffsll((long long)todo) - 1;
+            const int gl_o = gl0 + ol;
+            const int64_t t_o = mrz_bcast64(t, ol);
+            const int rank_o = mrz_lane_read(my_rank, ol);
+            const bool ins_o = mrz_lane_read((int)do_ins, ol) != 0;
+            int s_o = mrz_lane_read(s, ol), fe_o = -1;
+            int wslot_o = mrz_lane_read(wslot, ol), kind_o = mrz_lane_read(kind, ol), round_o = mrz_lane_read(round, ol);
+            int nsame_o = mrz_lane_read(nsame, ol);
+            bool evict_o = mrz_lane_read((int)evict, ol) != 0, cplx_o = mrz_lane_read((int)cplx, ol) != 0;
+            int why_o = mrz_lane_read(why, ol);
+            int64_t occ_t_o = mrz_bcast64(occ_t, ol), occ_off_o = mrz_bcast64(occ_off, ol);
+            mrz_ov ov_o;
+            if (USE_OV) {  // the straggler's overlay, broadcast to its wave
+                ov_o.n = mrz_lane_read(ovl.n, ol);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    ov_o.slot[k] = mrz_lane_read(ovl.slot[k], ol);
+                    ov_o.off[k] = mrz_bcast64(ovl.off[k], ol);
+                    ov_o.t[k] = mrz_bcast64(ovl.t[k], ol);
+                }
+            }
+            for (int cstep = 0; fe_o < 0; cstep++) {
+                if (cstep >= MRZ_WALK_COOP_STEPS) {
+                    cplx_o = true;
+                    if (!why_o) why_o = 1;
+                    break;
+                }
+                const int slot = (s_o + lane) & smask;
+                const mrz_slot e = mrz_tab_load(tab, slot, USE_OV ? &ov_o : nullptr);
+                const bool empty = (e.off | e.t) == 0;
+                const mrz_u64 m_empty = __ballot(empty);
+                const int fe_idx = m_empty ? __ffsll((long long)m_empty) - 1 : 64;
+                const mrz_u64 valid = mrz_low_mask(fe_idx);
+                const mrz_u64 m_same = __ballot(!empty && e.t == t_o) & valid;
+                if (ins_o && wslot_o < 0 && !evict_o) {
+                    const mrz_u64 m_worse = __ballot(!empty && (e.t & better) != better) & valid;
+                    const mrz_u64 m_lower = __ballot(!empty && mrz_ones_rank(e.t) < rank_o) & valid & ~m_worse;
+                    const mrz_u64 m_stop = m_worse | m_lower;
+                    const int ks = m_stop ? __ffsll((long long)m_stop) - 1 : 64;
+                    const int nq = __popcll(m_same & ~m_worse & mrz_low_mask(ks));
+                    if (round_o + nq >= max_chain) {
+                        evict_o = true;
+                        kind_o = 3;
+                        round_o = max_chain;
+                    } else {
+                        round_o += nq;
+                        if (ks < 64) {
+                            wslot_o = (s_o + ks) & smask;
+                            kind_o = ((m_worse >> ks) & 1) ? 1 : 2;
+                            if (kind_o == 2) {
+                                occ_t_o = mrz_bcast64(e.t, ks);
+                                occ_off_o = mrz_bcast64(e.off, ks);
+                            }
+                        } else if (fe_idx < 64) {
+                            wslot_o = (s_o + fe_idx) & smask;
+                            kind_o = 0;
+                        }
+                    }
+                }
+                // room for the new tag-equal entries: chunks are handed out by one lane, then everyone stores
+                const int nnew = __popcll(m_same);
+                if (nnew) {
+                    int need = nsame_o + nnew;
+                    if (need > MRZ_SMAX) need = MRZ_SMAX;
+                    for (int c = (nsame_o + 3) >> 2; c < (need + 3) >> 2; c++)
+                        if (lane == 0 && c >= S->nchunk[gl_o]) {
+                            const int id = atomicAdd(&S->pool_top, 1);
+                            S->chunk_id[gl_o][c] = id < MRZ_POOL ? (unsigned short)id : (unsigned short)0xffff;
+                            if (id < MRZ_POOL) S->nchunk[gl_o] = (unsigned char)(c + 1);
+                        }
+                    MRZ_WAVE_SYNC();
+                    bool bad = false;
+                    if ((m_same >> lane) & 1) {
+                        const int idx = nsame_o + __popcll(m_same & mrz_low_mask(lane));
+                        if (idx < MRZ_SMAX) {
+                            const int id = S->chunk_id[gl_o][idx >> 2];
+                            if (id == 0xffff)
+                                bad = true;
+                            else
+                                S->pool[id].e[idx & 3] =
+                                    (unsigned long long)e.off | ((unsigned long long)(unsigned)slot << MRZ_OFF_BITS);
+                        }
+                    }
+                    if (__ballot(bad)) {
+                        cplx_o = true;
+                        if (!why_o) why_o = 3;
+                    }
+                    nsame_o += nnew;
+                    if (nsame_o > MRZ_SMAX) {
+                        cplx_o = true;
+                        if (!why_o) why_o = 4;
+                    }
+                }
+                if (fe_idx < 64) fe_o = (s_o + fe_idx) & smask;
+                s_o += 64;
+            }
+            if (lane == ol) {
+                walking = false;
+                fe = fe_o;
+                wslot = wslot_o;
+                kind = kind_o;
+                round = round_o;
+                nsame = nsame_o;
+                evict = evict_o;
+                cplx = cplx_o;
+                why = why_o;
+                occ_t = occ_t_o;
+                occ_off = occ_off_o;
+            }
+        }
+        MRZ_WAVE_SYNC();
+    }
+    if (evict && max_chain > MRZ_SMAX) MRZ_CPLX(4);
+
+    // ---- walk of a displaced occupant (src/rzip.c:275-278) ----
+    int h2 = 0, w2 = -1, kind2 = -1, len2 = 0;
+    {
+        bool walking = go && !cplx && kind == 2;
+        const int rank2 = mrz_ones_rank(occ_t);
+        h2 = (int)(occ_t & C.slot_mask);
+        int s = h2, steps = 0, round2 = 0;
+        int ustep = 0;
+        while (true) {
+            const mrz_u64 m_walk = __ballot(walking);
+            if (!m_walk) break;
+            if (ustep >= MRZ_WALK_LANE_STEPS && __popcll(m_walk) <= MRZ_WALK_COOP_MAX) break;
+            ustep++;
+            if (walking) {
+                mrz_slot e[MRZ_WALK_SLOTS];
+#pragma unroll
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) e[k] = mrz_tab_load(tab, (s + k) & smask, ov);
+#pragma unroll
+                for (int k = 0; k < MRZ_WALK_SLOTS; k++) {
+                    if (!walking) continue;
+                    const int slot = (s + k) & smask;
+                    if ((e[k].off | e[k].t) == 0) {
+                        w2 = slot;
+                        kind2 = 0;
+                        walking = false;
+                    } else if ((e[k].t & better) != better) {
+                        w2 = slot;
+                        kind2 = 1;
+                        walking = false;
+                    } else if (mrz_ones_rank(e[k].t) < rank2) {
+                        MRZ_CPLX(2);  // second-level displacement: cooperative path
+                        walking = false;
+                    } else if (e[k].t == occ_t) {
+                        if (++round2 == max_chain) {
+                            MRZ_CPLX(2);
+                            walking = false;
+                        }
+                    }
+                }
+                s += MRZ_WALK_SLOTS;
+                if (walking && ++steps >= MRZ_WALK_STEPS) {
+                    MRZ_CPLX(1);
+                    walking = false;
+                }
+            }
+        }
+        for (mrz_u64 todo = __ballot(walking); todo; todo &= todo - 1) {
+            const int ol = __ffsll((long long)todo) - 1;
+            const int64_t ot = mrz_bcast64(occ_t, ol);
+            const int rk = mrz_lane_read(rank2, ol);
+            int s_o = mrz_lane_read(s, ol), r2 = mrz_lane_read(round2, ol);
+            int w2_o = -1, kind2_o = -1;
+            bool cplx_o = false, done = false;
+            mrz_ov ov_o;
+            if (USE_OV) {
+                ov_o.n = mrz_lane_read(ovl.n, ol);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    ov_o.slot[k] = mrz_lane_read(ovl.slot[k], ol);
+                    ov_o.off[k] = mrz_bcast64(ovl.off[k], ol);
+                    ov_o.t[k] = mrz_bcast64(ovl.t[k], ol);
+                }
+            }
+            for (int cstep = 0; !done; cstep++) {
+                if (cstep >= MRZ_WALK_COOP_STEPS) {
+                    cplx_o = true;
+                    break;
+                }
+                const int slot = (s_o + lane) & smask;
+                const mrz_slot e = mrz_tab_load(tab, slot, USE_OV ? &ov_o : nullptr);
+                const bool empty = (e.off | e.t) == 0;
+                const bool worse = !empty && (e.t & better) != better;
+                const bool lower = !empty && !worse && mrz_ones_rank(e.t) < rk;
+                const mrz_u64 m_empty = __ballot(empty), m_worse = __ballot(worse), m_lower = __ballot(lower);
+                const mrz_u64 m_stop = m_empty | m_worse | m_lower;
+                const int ks = m_stop ? __ffsll((long long)m_stop) - 1 : 64;
+                const int nq = __popcll(__ballot(!empty && !worse && !lower && e.t == ot) & mrz_low_mask(ks));
+                if (r2 + nq >= max_chain) {
+                    cplx_o = true;
+                    done = true;
+                } else if (ks < 64) {
+                    if ((m_lower >> ks) & 1)
+                        cplx_o = true;  // second-level displacement: cooperative path
+                    else {
+                        w2_o = (s_o + ks) & smask;
+                        kind2_o = ((m_empty >> ks) & 1) ? 0 : 1;
+                    }
+                    done = true;
+                } else {
+                    r2 += nq;
+                    s_o += 64;
+                }
+            }
+            if (lane == ol) {
+                walking = false;
+                w2 = w2_o;
+                kind2 = kind2_o;
+                if (cplx_o) MRZ_CPLX(2);
+            }
+        }
+        if (w2 >= 0) len2 = ((w2 - h2) & smask) + 1;
+    }
+    o.fe = fe;
+    o.wslot = wslot;
+    o.kind = kind;
+    o.nsame = nsame;
+    o.h2 = h2;
+    o.w2 = w2;
+    o.kind2 = kind2;
+    o.len2 = len2;
+    o.cplx = cplx;
+    o.why = why;
+    o.occ_t = occ_t;
+    o.occ_off = occ_off;
+}
+
+// cyclic interval test: does slot x lie in [a, a + la) (mod table size)?
+#undef MRZ_CPLX
+__device__ __forceinline__ bool mrz_in_range(int x, int a, int la, int smask) { return ((x - a) & smask) < la; }
+// do the cyclic intervals [a, a + la) and [b, b + lb) share a slot?
+__device__ __forceinline__ bool mrz_ranges_meet(int a, int la, int b, int lb, int smask) {
+    return la > 0 && lb > 0 && ((((b - a) & smask) < la) || (((a - b) & smask) < lb));
+}
+
+// ---- block hash of this batch's writes (phase B2) ----
+__device__ __forceinline__ unsigned mrz_bh_hash(unsigned block) { return (block * 2654435761u) >> (32 - 11); }
+
+__device__ static void mrz_bh_add(mrz_wide_lds *S, int slot, int gl) {
+    const unsigned key = ((unsigned)slot >> 6) + 1u;
+    unsigned i = mrz_bh_hash(key);
+    for (int n = 0; n < MRZ_BH_SIZE; n++) {
+        const unsigned k = atomicCAS(&S->bh_key[i], 0u, key);
+        if (k == 0u || k == key) {
+            const unsigned c = atomicAdd(&S->bh_cnt[i], 1u);
+            if (c < MRZ_BH_WRITERS) S->bh_lane[i][c] = (unsigned short)gl;
+            return;
+        }
+        i = (i + 1) & (MRZ_BH_SIZE - 1);
+    }
+}
+
+// the writes lane `wl` would make, as far as they are known before the scans: its insert slot (an evicting lane
+// overwrites one of the tag-equal entries of its own chain: any slot of [h, h + len1)), and the slot its displaced
+// occupant moves to.  Does one of them lie in [a, a + la) or [b, b + lb)?
+__device__ __forceinline__ bool mrz_writes_hit(const mrz_wide_lds *S, int wl, int a, int la, int b, int lb, int smask) {
+    const int k = S->kind[wl];
+    bool hit;
+    if (k == 3)
+        hit = mrz_ranges_meet(S->h[wl], S->len1[wl], a, la, smask) || mrz_ranges_meet(S->h[wl], S->len1[wl], b, lb, smask);
+    else {
+        const int ws = S->wslot[wl];
+        hit = (la > 0 && mrz_in_range(ws, a, la, smask)) || (lb > 0 && mrz_in_range(ws, b, lb, smask));
+        if (k == 2) {
+            const int w2 = S->w2[wl];
+            hit = hit || (la > 0 && mrz_in_range(w2, a, la, smask)) || (lb > 0 && mrz_in_range(w2, b, lb, smask));
+        }
+    }
+    return hit;
+}
+
+// Reader side: does an earlier lane of this batch write into [a, a + la) or [b, b + lb)?  Returns the number of
+// such lanes found (capped), their ids in wr[0..1]; -1 when a block has more writers than the hash records.
+__device__ static int mrz_bh_readers(const mrz_wide_lds *S, int gl, int a, int la, int b, int lb, int smask, int *wr) {
+    int found = 0;
+    for (int part = 0; part < 2; part++) {
+        const int r0 = part ? b : a, rl = part ? lb : la;
+        if (rl <= 0) continue;
+        const int last = ((r0 + rl - 1) & smask) >> 6;
+        for (int blk = r0 >> 6;; blk = (blk + 1) & (smask >> 6)) {
+            const unsigned key = (unsigned)blk + 1u;
+            unsigned i = mrz_bh_hash(key);
+            for (int n = 0; n < MRZ_BH_SIZE; n++) {
+                const unsigned k = S->bh_key[i];
+                if (k == 0u) break;
+                if (k == key) {
+                    const unsigned c = S->bh_cnt[i];
+                    if (c > MRZ_BH_WRITERS) {
+                        // more writers than recorded: an earlier one may be among them
+                        return -1;
+                    }
+                    for (unsigned j = 0; j < c; j++) {
+                        const int wl = S->bh_lane[i][j];
+                        if (wl >= gl) continue;
+                        if (!mrz_writes_hit(S, wl, a, la, b, lb, smask)) continue;
+                        bool dup = false;
+                        for (int z = 0; z < found && z < 2; z++) dup = dup || wr[z] == wl;
+                        if (!dup) {
+                            if (found < 2) wr[found] = wl;
+                            found++;
+                        }
+                    }
+                    break;
+                }
+                i = (i + 1) & (MRZ_BH_SIZE - 1);
+            }
+            if (blk == last) break;
+        }
+    }
+    return found;
+}
+
+// best of a lane's tag-equal entries under the current last_match, in probe order: first longest wins
+// (find_best_match, src/rzip.c:443-454)
+__device__ static void mrz_lane_best(const mrz_wide_lds *S, int gl, int nsame, int64_t q, int64_t floor_p, int64_t *blen,
+                                     int64_t *boff, int *brev, int *hits, int *misses, bool *need_long) {
+    int64_t best = 0, best_off = 0;
+    int best_rev = 0, h = 0, m = 0;
+    bool lng = false;
+    for (int k = 0; k < nsame; k++) {
+        const int c = S->chunk_id[gl][k >> 2];
+        const unsigned long long v = S->pool[c].e[k & 3];
+        const unsigned raw = S->pool[c].raw[k & 3];
+        const int64_t op = (int64_t)(v & MRZ_OFF_MASK);
+        int64_t ml;
+        int rv;
+        bool l;
+        mrz_pair_eval(raw, q, op, floor_p, &ml, &rv, &l);
+        lng = lng || l;
+        if (ml) {
+            if (ml > best) {
+                best = ml;
+                best_off = op - rv;
+                best_rev = rv;
+            }
+            h++;
+        } else
+            m++;
+    }
+    *blen = lng ? 0 : best;
+    *boff = best_off;
+    *brev = best_rev;
+    *hits = h;
+    *misses = m;
+    *need_long = lng;
+}
+
+// slot of the failing entry of rank `r` in the cull window
+__device__ __forceinline__ int mrz_cw_slot(const mrz_wide_lds *S, int64_t cw_base, int r) {
+    int lo = 0, hi = MRZ_CW_WORDS - 1;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (S->cwcum[mid] <= r)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return (int)(cw_base + lo * 64 + mrz_select64(S->cw[lo], r - S->cwcum[lo]));
+}
+
+struct mrz_wide_ret {
+    int used;        // candidates committed by this step
+    bool coop_next;  // the next candidate (the first after L.p) has to go through the cooperative path
+    bool ok;         // false: event list overflow
+    bool long_seen;  // a lane had entries beyond the 64-byte reach (scheduling hint)
+    bool skipped_out;  // an emitted match ended beyond the batch
+};
+
+// One wide batch.  All threads of the workgroup call it with identical L, width; every wave returns the same L.
+__device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds *S, const int64_t *__restrict__ tags,
+                                     const mrz_u64 *__restrict__ bitmap, int64_t seg_start, int64_t lim, int64_t nwords,
+                                     int width, int tid, int lane, int wave, int64_t *stat, mrz_wide_ret *ret) {
+    const uint8_t *__restrict__ buf = C.buf;
+    mrz_slot *tab = C.tab;
+    const int smask = (int)C.slot_mask;
+    const int max_chain = (int)C.max_chain;
+    const int64_t better = (L.min_mask << 1) | 1;
+    ret->used = 0;
+    ret->coop_next = false;
+    ret->ok = true;
+    ret->long_seen = false;
+    ret->skipped_out = false;
+    PROF_T0();
+
+    // ---- A: formation ----------------------------------------------------------------------------------
+    int64_t pos = L.p + 1;
+    if (pos < seg_start) pos = seg_start;
+    const int64_t w0 = (pos - seg_start) >> 6;
+    const int64_t widx = w0 + tid;
+    mrz_u64 w = widx < nwords ? bitmap[widx] : 0ull;
+    {
+        const int64_t lane_lo = seg_start + widx * 64;
+        if (pos > lane_lo) {
+            const int64_t sh = pos - lane_lo;
+            w = sh >= 64 ? 0ull : (w >> sh) << sh;
+        }
+        if (lim < lane_lo + 63) {
+            const int64_t keepbits = lim - lane_lo + 1;
+            w = keepbits <= 0 ? 0ull : (w & mrz_low_mask((int)keepbits));
+        }
+    }
+    for (int i = tid; i < MRZ_BH_SIZE; i += MRZ_W) {
+        S->bh_key[i] = 0u;
+        S->bh_cnt[i] = 0u;
+    }
+    if (tid == 0) {
+        S->pool_top = 0;
+        S->nw_cnt = 0;
+    }
+    S->nchunk[tid] = 0;
+    S->supp_w[tid] = (unsigned short)MRZ_W;
+    S->supp_w2[tid] = (unsigned short)MRZ_W;
+    // the cull window: entries ahead of tag_clean_ptr that fail `better` (only when this batch can reach the limit)
+    const int64_t cw_base = L.clean_ptr;
+    const bool want_cw = L.count + width > C.limit;
+    const int cw_len = want_cw ? MRZ_CW_WORDS * 64 : 0;
+    if (want_cw) {
+        for (int b = 0; b < MRZ_CW_WORDS / MRZ_SEQ_WAVES; b++) {
+            const int wi = b * MRZ_SEQ_WAVES + wave;
+            const int64_t slot = cw_base + (int64_t)wi * 64 + lane;
+            mrz_slot e;
+            e.off = 0;
+            e.t = 0;
+            if (slot < C.nslots) e = tab[slot];
+            const mrz_u64 m = __ballot(((e.off | e.t) != 0) && ((e.t & better) != better));
+            if (lane == 0) S->cw[wi] = m;
+        }
+    } else if (tid < MRZ_CW_WORDS)
+        S->cw[tid] = 0ull;
+    const int cnt = __popcll(w);
+    int total;
+    const int incl = mrz_wide_incl(cnt, S->wt1, lane, wave, &total);
+    S->pref[tid] = incl - cnt;
+    S->word[tid] = w;
+    __syncthreads();
+    if (wave == 0) {
+        const int c = lane < MRZ_CW_WORDS ? __popcll(S->cw[lane]) : 0;
+        const int ci = mrz_wave_incl_sum(c, lane);
+        if (lane < MRZ_CW_WORDS) S->cwcum[lane + 1] = ci;
+        if (lane == 0) S->cwcum[0] = 0;
+    }
+    const int nb = total < width ? total : width;
+    if (nb == 0) {
+        const int64_t wend = seg_start + (w0 + MRZ_W) * 64 - 1;
+        L.p = wend < lim ? wend : lim;
+        __syncthreads();
+        return;
+    }
+    const bool have = tid < nb;
+    int64_t q = 0, t = 0;
+    {
+        int wlo = 0, whi = MRZ_W - 1;
+        for (int it = 0; (1 << it) < MRZ_W; it++) {
+            const int mid = (wlo + whi + 1) >> 1;
+            if (S->pref[mid] <= tid)
+                wlo = mid;
+            else
+                whi = mid - 1;
+        }
+        if (have) {
+            q = seg_start + (w0 + wlo) * 64 + mrz_select64(S->word[wlo], tid - S->pref[wlo]);
+            t = tags[q - seg_start];
+        }
+    }
+    const bool act = have && (t & L.min_mask) == L.min_mask;
+    bool ins = act && (t & L.tag_mask) == L.tag_mask;
+    const bool loose = L.tag_mask != better;
+    S->q[tid] = have ? q : (int64_t)0x7fffffffffffffffll;
+    PROF_ADD(MRZ_ST_T_FORM);
+
+    // ---- B: walk -----------------------------------------------------------------------------------------
+    mrz_wl wl;
+    mrz_ov ov0;
+    ov0.n = 0;
+    mrz_wide_walk<false>(C, S, act, tid, lane, t, ins, better, ov0, wl);
+    bool cplx = act && wl.cplx;
+    bool conf = false;
+    ST_COUNT(MRZ_ST_X_WALK, cplx && wl.why == 1);
+    ST_COUNT(MRZ_ST_X_CASC, cplx && wl.why == 2);
+    ST_COUNT(MRZ_ST_X_POOL, cplx && wl.why == 3);
+    ST_COUNT(MRZ_ST_X_SAME, cplx && wl.why == 4);
+    int h = (int)(t & C.slot_mask);
+    int len1 = (act && !cplx) ? ((wl.fe - h) & smask) + 1 : 0;
+    int dep0 = -1, dep1 = -1;  // lanes whose writes this lane's (overlay) walk has assumed
+
+    // post-walk rules that involve the cull window; publishes the lane's facts
+    auto post_walk = [&]() {
+        if (act && !cplx) {
+            // a write that changes the set of failing entries inside the window would change the sweep
+            if (ins && cw_len > 0) {
+                if ((wl.kind == 1 || loose) && wl.kind != 3 && wl.wslot >= cw_base && wl.wslot < cw_base + cw_len) cplx = true;
+                if (wl.kind == 2 && (wl.kind2 == 1 || loose) && wl.w2 >= cw_base && wl.w2 < cw_base + cw_len) cplx = true;
+            }
+            // reads inside the window: an earlier lane's cull may empty a slot this lane has read
+            if (cw_len > 0 && (mrz_ranges_meet(h, len1, (int)cw_base, cw_len, smask) ||
+                               mrz_ranges_meet(wl.h2, wl.len2, (int)cw_base, cw_len, smask)))
+                conf = true;
+        }
+        S->h[tid] = h;
+        S->len1[tid] = (act && !cplx) ? len1 : 0;
+        S->h2[tid] = wl.h2;
+        S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
+        S->wslot[tid] = wl.wslot;
+        S->w2[tid] = wl.w2;
+        S->kind[tid] = (unsigned char)((act && !cplx && ins) ? wl.kind : 255);
+        S->kind2[tid] = (unsigned char)wl.kind2;
+        S->ns[tid] = (unsigned char)(wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX);
+        S->occ_off[tid] = wl.occ_off;
+        S->occ_t[tid] = wl.occ_t;
+    };
+    S->t[tid] = t;
+    {
+        const bool c0 = cplx;
+        post_walk();
+        (void)c0;
+        ST_COUNT(MRZ_ST_X_WIN, cplx && !c0);
+    }
+    // B2: the block hash of the writes, then every lane looks for earlier writers in its read ranges
+    if (act && !cplx && ins) {
+        if (wl.kind == 3) {
+            const int last = ((h + len1 - 1) & smask) >> 6;
+            for (int blk = h >> 6;; blk = (blk + 1) & (smask >> 6)) {
+                mrz_bh_add(S, blk << 6, tid);
+                if (blk == last) break;
+            }
+        } else {
+            mrz_bh_add(S, wl.wslot, tid);
+            if (wl.kind == 2) mrz_bh_add(S, wl.w2, tid);
+        }
+    }
+    PROF_ADD(MRZ_ST_T_WALK);
+    __syncthreads();
+    int wr[2] = { -1, -1 };
+    int nwr = 0;
+    if (act && !cplx) {
+        nwr = mrz_bh_readers(S, tid, h, len1, wl.h2, wl.len2, smask, wr);
+        if (nwr != 0) conf = true;
+    }
+    PROF_ADD(MRZ_ST_T_CONF);
+
+    // ---- B3: overlay walk.  A stale lane whose (one or two) earlier writers are themselves sound walks once more
+    // with those lanes' writes laid over the table -- what it would read had they been committed.  The common case
+    // is the next position carrying the same tag (the XOR tag only sees the multiset of the 31 bytes).
+    {
+        const bool win_stale = act && !cplx && conf && nwr == 0;  // stale only because of the cull window
+        S->lf[tid] = (unsigned char)((conf ? 1 : 0) | (cplx ? 2 : 0) | (act ? 4 : 0));
+        __syncthreads();
+        bool elig = act && !cplx && conf && !win_stale && nwr >= 1 && nwr <= 2;
+        int cwhy = 0;  // why a stale lane could not be repaired here (diagnostics)
+        if (act && !cplx && conf && !elig) cwhy = win_stale ? 1 : 4;
+        mrz_ov ov;
+        ov.n = 0;
+        int ov_src[4] = { -1, -1, -1, -1 };  // writer lane * 2 + (0: its insert slot, 1: its occupant's new slot)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ov.slot[k] = -1;
+            ov.off[k] = 0;
+            ov.t[k] = 0;
+        }
+        if (elig) {
+            if (nwr == 2 && wr[0] > wr[1]) {
+                const int z = wr[0];
+                wr[0] = wr[1];
+                wr[1] = z;
+            }
+            for (int k = 0; k < nwr; k++) {
+                const int i = wr[k];
+                const int ki = S->kind[i];
+                if ((S->lf[i] & 3) != 0 || ki == 3 || ki == 255) {
+                    elig = false;
+                    if (!cwhy) cwhy = ki == 3 ? 2 : 3;
+                }
+            }
+            // the window read rule would make it stale again anyway
+            if (cw_len > 0 && (mrz_ranges_meet(h, len1, (int)cw_base, cw_len, smask) ||
+                               mrz_ranges_meet(wl.h2, wl.len2, (int)cw_base, cw_len, smask))) {
+                elig = false;
+                if (!cwhy) cwhy = 1;
+            }
+        }
+        if (elig) {
+            for (int k = 0; k < nwr; k++) {
+                const int i = wr[k];
+                if (S->kind[i] == 2) {
+                    ov.slot[ov.n] = S->w2[i];
+                    ov.off[ov.n] = S->occ_off[i];
+                    ov.t[ov.n] = S->occ_t[i];
+                    ov_src[ov.n] = i * 2 + 1;
+                    ov.n++;
+                }
+                ov.slot[ov.n] = S->wslot[i];
+                ov.off[ov.n] = S->q[i];
+                ov.t[ov.n] = S->t[i];
+                ov_src[ov.n] = i * 2;
+                ov.n++;
+            }
+        }
+        const mrz_u64 m_el = __ballot(elig);
+        int n_el;
+        (void)mrz_wide_incl(lane == 0 ? __popcll(m_el) : 0, S->wt5, lane, wave, &n_el);
+        if (n_el) {  // uniform
+            ST_ADD(MRZ_ST_OVL, n_el);
+            mrz_wl wn;
+            mrz_wide_walk<true>(C, S, elig, tid, lane, t, ins, better, ov, wn);
+            bool good = false;
+            if (elig) {
+                good = !wn.cplx && wn.kind != 3;
+                // A lane that overwrites (or displaces) an entry one of its writers has just put there: inside one
+                // segment both would store to the same slot.  The later store is the one that stays, so the writer is
+                // told to leave its store out when both commit together (supp_w / supp_w2, looked at in the commit).
+                // Only the insert slot may tie; an occupant moving onto a writer's slot waits for its turn.
+                int tie_src = -1;
+                if (good && ins)
+                    for (int k = 0; k < 4; k++)
+                        if (k < ov.n) {
+                            if (wn.kind == 2 && ov.slot[k] == wn.w2) {
+                                good = false;
+                                cwhy = 6;
+                            } else if (ov.slot[k] == wn.wslot)
+                                tie_src = ov_src[k];  // the last writer of that slot (overlay order = lane order)
+                        }
+                const int nlen1 = good ? ((wn.fe - h) & smask) + 1 : 0;
+                if (good) {
+                    // no other earlier writer may reach into what it has read now
+                    int wr2[2] = { -1, -1 };
+                    const int n2 = mrz_bh_readers(S, tid, h, nlen1, wn.h2, wn.len2, smask, wr2);
+                    if (n2 < 0 || n2 > nwr) good = false;
+                    for (int k = 0; k < n2 && k < 2 && good; k++)
+                        if (wr2[k] != wr[0] && (nwr < 2 || wr2[k] != wr[1])) good = false;
+                    if (cw_len > 0 && (mrz_ranges_meet(h, nlen1, (int)cw_base, cw_len, smask) ||
+                                       mrz_ranges_meet(wn.h2, wn.len2, (int)cw_base, cw_len, smask)))
+                        good = false;
+                    if (ins && cw_len > 0) {
+                        if ((wn.kind == 1 || loose) && wn.wslot >= cw_base && wn.wslot < cw_base + cw_len) good = false;
+                        if (wn.kind == 2 && (wn.kind2 == 1 || loose) && wn.w2 >= cw_base && wn.w2 < cw_base + cw_len)
+                            good = false;
+                    }
+                }
+                // its new writes: the lanes behind it have to look at them again
+                if (good && ins) {
+                    const int nn = wn.kind == 2 ? 2 : 1;
+                    const int at = atomicAdd(&S->nw_cnt, nn);
+                    if (at + nn > MRZ_NW_MAX)
+                        good = false;
+                    else {
+                        S->nw_slot[at] = wn.wslot;
+                        S->nw_lane[at] = (unsigned short)tid;
+                        if (nn == 2) {
+                            S->nw_slot[at + 1] = wn.w2;
+                            S->nw_lane[at + 1] = (unsigned short)tid;
+                        }
+                    }
+                }
+                if (good && tie_src >= 0) {
+                    if (tie_src & 1)
+                        S->supp_w2[tie_src >> 1] = (unsigned short)tid;
+                    else
+                        S->supp_w[tie_src >> 1] = (unsigned short)tid;
+                }
+                if (good) {
+                    wl = wn;
+                    len1 = nlen1;
+                    conf = false;
+                    dep0 = wr[0];
+                    dep1 = nwr == 2 ? wr[1] : -1;
+                    S->len1[tid] = len1;
+                    S->h2[tid] = wl.h2;
+                    S->len2[tid] = wl.len2;
+                    S->wslot[tid] = wl.wslot;
+                    S->w2[tid] = wl.w2;
+                    S->kind[tid] = (unsigned char)(ins ? wl.kind : 255);
+                    S->kind2[tid] = (unsigned char)wl.kind2;
+                    S->ns[tid] = (unsigned char)(wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX);
+                    S->occ_off[tid] = wl.occ_off;
+                    S->occ_t[tid] = wl.occ_t;
+                }
+                if (!good && !cwhy) cwhy = 5;
+                // a lane whose overlay walk failed keeps the facts of its first walk published: they are what the
+                // lanes behind it were checked against, and it walks again when its turn comes
+            }
+            __syncthreads();
+            // every lane whose walk stands looks at the new writes of the overlay lanes before it
+            int nw = S->nw_cnt;
+            if (nw > MRZ_NW_MAX) nw = MRZ_NW_MAX;
+            if (act && !cplx && !conf) {
+                for (int k = 0; k < nw; k++) {
+                    const int wlane = S->nw_lane[k];
+                    if (wlane >= tid) continue;
+                    const int sl = S->nw_slot[k];
+                    if ((len1 > 0 && mrz_in_range(sl, h, len1, smask)) || (wl.len2 > 0 && mrz_in_range(sl, wl.h2, wl.len2, smask))) {
+                        conf = true;
+                        cwhy = 7;
+                    }
+                }
+            }
+#ifdef MRZ_SEQ_STATS
+            {
+                const mrz_u64 mg = __ballot(elig && good && !conf);
+                int tg;
+                (void)mrz_wide_incl(lane == 0 ? __popcll(mg) : 0, S->wt3, lane, wave, &tg);
+                ST_ADD(MRZ_ST_OVL_OK, tg);
+            }
+#endif
+        }
+        ST_COUNT(MRZ_ST_C_WIN, conf && cwhy == 1);
+        ST_COUNT(MRZ_ST_C_EVICT, conf && cwhy == 2);
+        ST_COUNT(MRZ_ST_C_DEEP, conf && cwhy == 3);
+        ST_COUNT(MRZ_ST_C_MANY, conf && cwhy == 4);
+        ST_COUNT(MRZ_ST_C_FAIL, conf && cwhy == 5);
+        ST_COUNT(MRZ_ST_C_TIE, conf && cwhy == 6);
+        ST_COUNT(MRZ_ST_C_NW, conf && cwhy == 7);
+    }
+    PROF_ADD(MRZ_ST_T_REWALK);
+
+    // ---- C: pairs (lanes whose walk stands) ----------------------------------------------------------------
+    auto do_pairs = [&](bool need) {
+        const int ns = need ? (wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX) : 0;
+        int P;
+        const int pincl = mrz_wide_incl(ns, S->wt3, lane, wave, &P);
+        const int pb = pincl - ns;
+        S->pbase[tid] = pb;
+        for (int k = 0; k < ns; k++) S->pair_owner[pb + k] = (unsigned short)tid;
+        __syncthreads();
+        for (int i = tid; i < P; i += MRZ_W) {
+            const int o = S->pair_owner[i];
+            const int k = i - S->pbase[o];
+            const int c = S->chunk_id[o][k >> 2];
+            const int64_t op = (int64_t)(S->pool[c].e[k & 3] & MRZ_OFF_MASK);
+            S->pool[c].raw[k & 3] = (unsigned short)mrz_lane_probe_raw(buf, S->q[o], op, C.end);
+        }
+        __syncthreads();
+    };
+    do_pairs(act && !cplx && !conf);
+    PROF_ADD(MRZ_ST_T_PAIRS);
+    ST_ADD(MRZ_ST_BATCHES, 1);
+    ST_ADD(MRZ_ST_FORMED, nb);
+#ifdef MRZ_SEQ_STATS
+    {
+        const mrz_u64 mc = __ballot(conf);
+        int tc;
+        const int ic = mrz_wide_incl(lane == 0 ? __popcll(mc) : 0, S->wt5, lane, wave, &tc);
+        (void)ic;
+        ST_ADD(MRZ_ST_CONF0, tc);
+    }
+#endif
+
+    // ---- E: commit in segments ---------------------------------------------------------------------------
+    int64_t cb_len = 0, cb_off = 0, cb_floor = -1;
+    int cb_rev = 0, cb_h = 0, cb_m = 0;
+    bool cb_have = false, cb_long = false, cb_resolved = false;
+    int s = 0, cw_used = 0, committed = 0, iters = 0;
+    while (true) {
+        if (++iters > 8 * MRZ_W) {  // cannot happen: every iteration commits, drops or repairs a lane
+            if (tid == 0) C.st->error = 3;
+            ret->ok = false;
+            break;
+        }
+        const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
+        const bool inb = have && tid >= s;
+        if (inb && act && !cplx && !conf) {
+            if (!cb_have || (floor_p != cb_floor && (cb_resolved || q - floor_p <= 64))) {
+                mrz_lane_best(S, tid, wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX, q, floor_p, &cb_len, &cb_off, &cb_rev, &cb_h,
+                              &cb_m, &cb_long);
+                cb_have = true;
+                cb_resolved = false;
+                cb_floor = floor_p;
+                S->boff[tid] = cb_off;
+                S->brev[tid] = cb_rev;
+            }
+        }
+        const bool stop = inb && act && (cplx || conf || cb_long);
+        {
+            const int f = mrz_wave_first(stop, wave, nb);
+            if (lane == 0) S->wmin[0][wave] = f;
+        }
+        __syncthreads();
+        const int x = mrz_wide_min_read(S->wmin[0]);
+        if (x == s) {
+            // ---- the stop lane is next: bring it into a committable state, or hand it to the cooperative path
+            if (tid == x) S->ctl[MRZ_CTL_STOPKIND] = cplx ? 1 : (conf ? 2 : 3);
+            __syncthreads();
+            const int sk = S->ctl[MRZ_CTL_STOPKIND];
+            if (sk == 1 || sk == 2) {
+                // A lane the batch cannot vouch for -- stale (an earlier lane wrote into what it read) or beyond the
+                // per-lane walk (long chain, deep cascade) -- goes through the cooperative path right here: wave 0
+                // replays this one candidate in full against the table as committed so far, the batch goes on behind it.
+                ST_ADD(sk == 1 ? MRZ_ST_CUT_CPLX : MRZ_ST_REWALK, 1);
+                const int64_t pre_min = L.min_mask, pre_tag = L.tag_mask, pre_events = L.n_events;
+                if (wave == 0) {
+                    L.p = S->q[x];
+                    const bool okc = mrz_seq_candidate(C, L, &S->coop, S->t[x], lane, stat);
+                    if (lane == 0) {
+                        S->Lp = L;
+                        S->ctl[MRZ_CTL_OK] = okc ? 1 : 0;
+                    }
+                }
+                __syncthreads();
+                L = S->Lp;
+                committed += 1;
+                if (!mrz_uni(S->ctl[MRZ_CTL_OK])) {
+                    ret->ok = false;
+                    break;
+                }
+                const int nwx = mrz_uni(S->coop.n_written);
+                const int64_t cullx = mrz_uni64(S->coop.cull_slot);
+                bool stop_batch = L.min_mask != pre_min || L.tag_mask != pre_tag;
+                // its cull must be the one the window expects next; its insert must not have touched the window
+                if (cullx >= 0) {
+                    if (cw_len == 0 || cw_used >= S->cwcum[MRZ_CW_WORDS] || mrz_cw_slot(S, cw_base, cw_used) != (int)cullx)
+                        stop_batch = true;
+                    else
+                        cw_used++;
+                }
+                for (int k = 0; k < nwx; k++) {
+                    const int64_t hs = S->coop.pend_h[k];
+                    if (cw_len > 0 && hs >= cw_base && hs < cw_base + cw_len) stop_batch = true;
+                }
+                // its writes against the reads of the lanes behind it; lanes that had laid its speculated writes over
+                // their walk are stale as well
+                if (have && tid > x && act && !cplx && !conf) {
+                    if (dep0 == x || dep1 == x) conf = true;
+                    for (int k = 0; k < nwx && !conf; k++) {
+                        const int hs = (int)S->coop.pend_h[k];
+                        if ((len1 > 0 && mrz_in_range(hs, h, len1, smask)) || (wl.len2 > 0 && mrz_in_range(hs, wl.h2, wl.len2, smask)))
+                            conf = true;
+                    }
+                    if (cullx >= 0 && ((len1 > 0 && mrz_in_range((int)cullx, h, len1, smask)) ||
+                                       (wl.len2 > 0 && mrz_in_range((int)cullx, wl.h2, wl.len2, smask))))
+                        conf = true;
+                }
+                int s_next = x + 1;
+                if (L.n_events != pre_events) {
+                    ST_ADD(MRZ_ST_EMITS, 1);
+                    const int64_t q_e = S->q[x];
+                    if (L.last_match >= q_e) {
+                        int lo = x + 1, hi = nb;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (S->q[mid] > L.last_match)
+                                hi = mid;
+                            else
+                                lo = mid + 1;
+                        }
+                        s_next = lo;
+                        if (s_next >= nb) {
+                            ret->skipped_out = true;
+                            ST_ADD(MRZ_ST_SKIPOUT, 1);
+                        }
+                    } else {
+                        ST_ADD(MRZ_ST_BACKJUMP, 1);
+                        s_next = x;  // comes by q_e again, after its own insert: the cooperative path once more
+                        if (tid == x) conf = true;
+                    }
+                    if (have && tid >= s_next && ((dep0 > x && dep0 < s_next) || (dep1 > x && dep1 < s_next))) conf = true;
+                }
+                s = s_next;
+                PROF_ADD(MRZ_ST_T_REWALK);
+                __syncthreads();
+                if (stop_batch || s >= nb) break;
+                continue;
+            }
+            // sk == 3: tag-equal entries beyond the 64-byte reach: wave 0 measures them exactly (striped rounds,
+            // compare farm) and folds the lane's entries in probe order
+            ST_ADD(MRZ_ST_LONGRES, 1);
+            ret->long_seen = true;
+            if (wave == 0) {
+                const int nsx = S->ns[x];
+                const int64_t qx = S->q[x];
+                if (lane < nsx) {
+                    const int c = S->chunk_id[x][lane >> 2];
+                    const unsigned long long v = S->pool[c].e[lane & 3];
+                    const int64_t op = (int64_t)(v & MRZ_OFF_MASK);
+                    int64_t ml;
+                    int rv;
+                    bool l;
+                    mrz_pair_eval(S->pool[c].raw[lane & 3], qx, op, floor_p, &ml, &rv, &l);
+                    S->coop.same_off[lane] = op;
+                    S->coop.pair_res[lane] = l ? -1 : (int)((ml << 8) | rv);
+                }
+                MRZ_WAVE_SYNC();
+                int64_t xb = 0, xoff = 0, xrev = 0;
+                int xh = 0, xm = 0;
+                mrz_resolve_entries(C, L, &S->coop, qx, nsx, lane, stat, &xb, &xoff, &xrev, &xh, &xm);
+                if (lane == 0) {
+                    S->res64[0] = xb;
+                    S->res64[1] = xoff;
+                    S->res64[2] = xrev;
+                    S->res64[3] = ((int64_t)xh << 32) | (int64_t)xm;
+                }
+            }
+            __syncthreads();
+            if (tid == x) {
+                cb_len = S->res64[0];
+                cb_off = S->res64[1];
+                cb_rev = (int)S->res64[2];
+                cb_h = (int)(S->res64[3] >> 32);
+                cb_m = (int)(S->res64[3] & 0xffffffffll);
+                cb_long = false;
+                cb_have = true;
+                cb_resolved = true;
+                cb_floor = floor_p;
+                S->boff[tid] = cb_off;
+                S->brev[tid] = cb_rev;
+            }
+            PROF_ADD(MRZ_ST_T_LONG);
+            continue;
+        }
+
+        // ---- scans over the segment [s, x) -------------------------------------------------------------
+        ST_ADD(MRZ_ST_SEGMENTS, 1);
+        const bool inseg = inb && tid < x;
+        const bool a_ins = inseg && ins;  // act, not cplx, not stale
+        const bool a_ev = a_ins && wl.kind == 3;
+        const int d = a_ins ? (wl.kind == 0 ? 1 : (wl.kind == 2 ? (wl.kind2 == 0 ? 1 : 0) : 0)) : 0;
+        int dummy;
+        const int i1 = mrz_wide_incl(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wt1, lane, wave, &dummy);
+        S->A1[tid] = i1;
+        int wslot = wl.wslot;
+        if (a_ev) {
+            // victim_round for evicting lanes (static victim_round, src/rzip.c:259,283-289)
+            const int er = ((i1 >> 10) & 1023) - 1;
+            const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
+            wslot = (int)(mrz_pool_get(S, tid, vr) >> MRZ_OFF_BITS);
+        }
+        // hash_count before each lane: saturating prefix sum of the per-lane deltas
+        int64_t c_before = L.count + ((i1 & 1023) - d);
+        if (c_before > C.limit) c_before = C.limit;
+        const bool cull = a_ins && (c_before + d > C.limit);
+        const mrz_u64 i2 = mrz_wide_incl64((cull ? 1ull : 0ull) | ((mrz_u64)((inseg && act) ? cb_h : 0) << 16) |
+                                               ((mrz_u64)((inseg && act) ? cb_m : 0) << 32),
+                                           S->wt2, lane, wave);
+        S->A2[tid] = i2;
+        int cslot = -1;
+        bool overflow = false;
+        if (cull) {
+            const int cr = cw_used + (int)(i2 & 0xffffu) - 1;
+            if (cr >= S->cwcum[MRZ_CW_WORDS])
+                overflow = true;  // the sweep leaves the window (or wraps / promotes)
+            else
+                cslot = mrz_cw_slot(S, cw_base, cr);
+        }
+        // ---- the lazy-match fold (src/rzip.c:586-599) as a prefix maximum: first longest wins ---------------
+        const int rel = tid - s + 1;
+        const mrz_u64 key = (inseg && act) ? (((mrz_u64)cb_len << 10) | (mrz_u64)(1023 - rel)) : 0ull;
+        mrz_u64 K = mrz_wide_inclmax64(key, S->wt4, lane, wave);
+        {
+            const mrz_u64 k0 = ((mrz_u64)L.cur_len << 10) | 1023ull;
+            if (k0 > K) K = k0;
+        }
+        S->fkey[tid] = K;
+        bool emit = false;
+        if (inseg && act) {
+            const int64_t curlen = (int64_t)(K >> 10);
+            const int arel = 1023 - (int)(K & 1023ull);
+            const int64_t curp = arel == 0 ? L.cur_p : S->q[s + arel - 1] - S->brev[s + arel - 1];
+            emit = curlen >= MRZ_MIN_MATCH && (curlen >= MRZ_GREAT_MATCH || q >= curp + MRZ_MIN_MATCH);
+        }
+        {
+            const int fe_ = mrz_wave_first(emit, wave, MRZ_W);
+            const int fo_ = mrz_wave_first(overflow, wave, MRZ_W);
+            const int fc_ = mrz_wave_first(cull, wave, MRZ_W);
+            if (lane == 0) {
+                S->wmin[1][wave] = fe_;
+                S->wmin[2][wave] = fo_;
+                S->wmin[3][wave] = fc_;
+            }
+        }
+        __syncthreads();
+        const int e_lane = mrz_wide_min_read(S->wmin[1]);
+        const int o_lane = mrz_wide_min_read(S->wmin[2]);
+        const int c_lane = mrz_wide_min_read(S->wmin[3]);
+        int y = x;
+        bool end_batch = false;
+        if (o_lane < y) {
+            y = o_lane;
+            end_batch = true;
+        }
+        // the first cull ever switches the insert mask (:583): nothing after it in this batch
+        if (loose && c_lane + 1 <= y) {
+            y = c_lane + 1;
+            end_batch = true;
+        }
+        bool emission = false;
+        if (e_lane + 1 <= y) {
+            y = e_lane + 1;
+            emission = true;
+            end_batch = false;
+            if (loose && c_lane + 1 <= y) end_batch = true;
+        }
+        if (y == s) {
+            // the very next lane cannot be served from the cull window: a fresh batch reloads it; if even a fresh
+            // window has nothing (sweep wrap, mask promotion) the cooperative path takes the candidate
+            if (s == 0 && cw_used == 0) ret->coop_next = true;
+            ST_ADD(MRZ_ST_CUT_OVERFLOW, 1);
+            break;
+        }
+
+        // ---- commit [s, y) ---------------------------------------------------------------------------------
+        if (inseg && tid < y && ins) {
+            if (wl.kind == 2 && S->supp_w2[tid] >= y) {
+                mrz_slot oc;
+                oc.off = wl.occ_off;
+                oc.t = wl.occ_t;
+                tab[wl.w2] = oc;
+            }
+            if (S->supp_w[tid] >= y) {
+                mrz_slot nw;
+                nw.off = q;
+                nw.t = t;
+                tab[wslot] = nw;
+            }
+            if (cslot >= 0) {
+                mrz_slot z;
+                z.off = 0;
+                z.t = 0;
+                tab[cslot] = z;
+            }
+        }
+        {
+            const int a1 = S->A1[y - 1];
+            const mrz_u64 a2 = S->A2[y - 1];
+            const int dsum = a1 & 1023, esum = (a1 >> 10) & 1023, isum = (a1 >> 20) & 1023;
+            const int csum = (int)(a2 & 0xffffu), hsum = (int)((a2 >> 16) & 0xffffu), msum = (int)(a2 >> 32);
+            L.inserts += isum;
+            int64_t cnew = L.count + dsum;
+            if (cnew > C.limit) cnew = C.limit;
+            L.count = cnew;
+            if (csum) {
+                L.clean_ptr = mrz_cw_slot(S, cw_base, cw_used + csum - 1);
+                L.tag_mask = better;
+                cw_used += csum;
+            }
+            if (esum) L.victim_round = (int64_t)(((unsigned)L.victim_round + (unsigned)esum) % (unsigned)max_chain);
+            L.tag_hits += hsum;
+            L.tag_misses += msum;
+            const mrz_u64 Ky = S->fkey[y - 1];
+            const int arel = 1023 - (int)(Ky & 1023ull);
+            if (arel != 0) {
+                const int a = s + arel - 1;
+                L.cur_len = (int64_t)(Ky >> 10);
+                L.cur_p = S->q[a] - S->brev[a];
+                L.cur_ofs = S->boff[a];
+            }
+            L.p = S->q[y - 1];
+            committed += y - s;
+        }
+        int s_next = y;
+        if (emission) {
+            ST_ADD(MRZ_ST_EMITS, 1);
+            const int64_t q_e = L.p;
+            // the emission itself (put_literal / put_match happen in the encoder kernels)
+            if (L.n_events >= C.event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
+                if (tid == 0) C.st->error = 1;
+                ret->ok = false;
+                break;
+            }
+            if (tid == 0) {
+                mrz_event ev;
+                ev.p = L.cur_p;
+                ev.ofs = L.cur_ofs;
+                ev.len = L.cur_len;
+                C.events[L.n_events] = ev;
+            }
+            L.n_events++;
+            L.last_len = L.cur_len;
+            L.last_match = L.cur_p + L.cur_len;
+            L.cur_p = L.p = L.last_match;
+            L.cur_len = 0;
+            if (L.last_match >= q_e) {
+                // the lanes inside the match are dropped: first lane behind it
+                int lo = y, hi = nb;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (S->q[mid] > L.last_match)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                s_next = lo;
+                if (s_next >= nb) {
+                    ret->skipped_out = true;
+                    ST_ADD(MRZ_ST_SKIPOUT, 1);
+                }
+            } else {
+                // the match ends before the emitting position: the loop goes BACK (p = last_match, :596) and comes
+                // by q_e again -- the only candidate of (last_match, q_e] -- after its own insert
+                ST_ADD(MRZ_ST_BACKJUMP, 1);
+                s_next = y - 1;
+                if (tid == y - 1) {
+                    conf = true;
+                    cb_have = false;
+                }
+            }
+        }
+        // lanes that had laid the writes of a dropped lane over their walk are stale
+        if (emission && have && tid >= s_next && (dep0 >= 0 || dep1 >= 0)) {
+            if ((dep0 >= y && dep0 < s_next) || (dep1 >= y && dep1 < s_next)) conf = true;
+        }
+        s = s_next;
+        __syncthreads();  // the commits are in the table; the scan arrays may be reused
+        if (end_batch || s >= nb) break;
+    }
+    PROF_ADD(MRZ_ST_T_LOOP);
+    // the window ran dry: skip its empty rest
+    if (!ret->coop_next && ret->ok && s >= nb && nb == total && L.p < seg_start + (w0 + MRZ_W) * 64 - 1 &&
+        L.last_match <= S->q[nb - 1]) {
+        const int64_t wend = seg_start + (w0 + MRZ_W) * 64 - 1;
+        const int64_t np = wend < lim ? wend : lim;
+        if (np > L.p) L.p = np;
+    }
+    ST_ADD(MRZ_ST_COMMITTED, committed);
+    ret->used = committed;
+    __syncthreads();
+}

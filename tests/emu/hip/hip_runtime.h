@@ -85,6 +85,8 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { unsigned o = *p; if (o == cmp) *p = v; return o; }
+static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
 // ---- runtime API subset -----------------------------------------------------

@@ -5,10 +5,18 @@ import torch
 import modern_rzip_amd as m
 from modern_rzip_amd import workloads as w
 
+PROF = "--prof" in sys.argv
+if PROF:
+    sys.argv.remove("--prof")
+    os.environ["MRZ_PRINT_PROF"] = "1"
+    LIB = m.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_prof", "libmrzgpu_prof.so"))
+else:
+    LIB = m.load_library()
+
 def run(name, data, level=7):
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda() if isinstance(data, bytes) else data
     n = t.numel()
-    with m.RzipContext(level=level, max_chunk=n) as ctx:
+    with m.RzipContext(level=level, max_chunk=n, lib=LIB) as ctx:
         ctx.set_profiling(True)
         ctx.rzip_chunk(t, fetch=False)
         t0 = time.perf_counter()
