@@ -479,7 +479,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                          "t_form", "t_walk", "t_conf", "t_pairs", "t_loop", "t_rewalk", "t_long", "t_seq",
                                          "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
                                          "f_fold", "s_tab", "s_pair", "s_ins", "ovl", "ovl_ok", "x_walk", "x_casc", "x_pool",
-                                         "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw" };
+                                         "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw", "t_ovl",
+                                         "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit" };
         for (int k = 0; k < 64; k++) if (names[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;

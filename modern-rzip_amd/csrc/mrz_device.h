@@ -91,14 +91,55 @@ __device__ __forceinline__ int mrz_nth_set(mrz_u64 m, int k) {
 // trailing-ones rank used by lesser_bitness (src/rzip.c:248-252): ffsll(~t)
 __device__ __forceinline__ int mrz_ones_rank(int64_t t) { return __ffsll((long long)~t); }
 
-// inclusive prefix sum over the wave
+// inclusive prefix sum over the wave.  On the device: DPP row shifts inside the 16-lane rows, then the two row
+// broadcasts (6 VALU instructions, no LDS crossbar); the emulator build takes the shuffle form.
 __device__ __forceinline__ int mrz_wave_incl_sum(int v, int lane) {
+#ifdef __HIP_DEVICE_COMPILE__
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+#else
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl(v, lane - d >= 0 ? lane - d : lane, MRZ_WAVE);
         if (lane >= d) v += o;
     }
     return v;
+#endif
+}
+
+// inclusive prefix maximum of unsigned 64-bit keys over the wave (0 is the neutral element)
+__device__ __forceinline__ mrz_u64 mrz_wave_incl_max64(mrz_u64 v, int lane) {
+#ifdef __HIP_DEVICE_COMPILE__
+    (void)lane;
+#define MRZ_DPP_MAX64(ctrl, rmask, bc)                                                                        \
+    do {                                                                                                      \
+        const uint32_t lo__ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rmask, 0xf, bc);        \
+        const uint32_t hi__ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rmask, 0xf, bc); \
+        const mrz_u64 o__ = ((mrz_u64)hi__ << 32) | lo__;                                                     \
+        v = o__ > v ? o__ : v;                                                                                \
+    } while (0)
+    MRZ_DPP_MAX64(0x111, 0xf, true);
+    MRZ_DPP_MAX64(0x112, 0xf, true);
+    MRZ_DPP_MAX64(0x114, 0xf, true);
+    MRZ_DPP_MAX64(0x118, 0xf, true);
+    MRZ_DPP_MAX64(0x142, 0xa, false);
+    MRZ_DPP_MAX64(0x143, 0xc, false);
+#undef MRZ_DPP_MAX64
+    return v;
+#else
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const mrz_u64 o = (mrz_u64)mrz_shfl64((int64_t)v, lane - d >= 0 ? lane - d : lane);
+        if (lane >= d && o > v) v = o;
+    }
+    return v;
+#endif
 }
 
 // position of the k-th (0-based) set bit of w; w must have more than k bits set

@@ -62,7 +62,8 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        MRZ_ST_T_SEQ, MRZ_ST_FARMED, MRZ_ST_L_POST, MRZ_ST_L_STRIPE, MRZ_ST_L_BWD, MRZ_ST_L_WAIT, MRZ_ST_L_ROUNDS,
        MRZ_ST_F_POST, MRZ_ST_F_WAIT, MRZ_ST_F_FOLD, MRZ_ST_S_TAB, MRZ_ST_S_PAIR, MRZ_ST_S_INS, MRZ_ST_OVL, MRZ_ST_OVL_OK,
        MRZ_ST_X_WALK, MRZ_ST_X_CASC, MRZ_ST_X_POOL, MRZ_ST_X_WIN, MRZ_ST_X_SAME, MRZ_ST_C_WIN, MRZ_ST_C_EVICT, MRZ_ST_C_DEEP,
-       MRZ_ST_C_MANY, MRZ_ST_C_FAIL, MRZ_ST_C_TIE, MRZ_ST_C_NW, MRZ_ST_N };
+       MRZ_ST_C_MANY, MRZ_ST_C_FAIL, MRZ_ST_C_TIE, MRZ_ST_C_NW, MRZ_ST_T_OVL, MRZ_ST_H_PRE, MRZ_ST_H_CAND, MRZ_ST_H_POST,
+       MRZ_ST_T_SCAN, MRZ_ST_T_FOLD, MRZ_ST_T_COMMIT, MRZ_ST_N };
 
 struct mrz_seq_args {
     const uint8_t *buf;
@@ -76,6 +77,14 @@ struct mrz_seq_args {
     void *gmailbox;           // mrz_gmailbox in device memory, zeroed by the host before every launch
     int n_helpers;            // helper workgroups in this launch (grid size - 1)
 };
+
+// workgroup-scope accesses to LDS control words
+__device__ __forceinline__ int mrz_mb_load(int *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void mrz_mb_store(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 #ifndef MRZ_STRIPE_PIECES
 #define MRZ_STRIPE_PIECES 4

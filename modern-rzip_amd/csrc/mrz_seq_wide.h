@@ -41,6 +41,10 @@
 #define MRZ_BH_WRITERS 3
 #define MRZ_CW_WORDS 32               // cull window: 32 x 64 slots ahead of tag_clean_ptr
 #define MRZ_NW_MAX 192
+#define MRZ_XW_MAX 48
+#ifndef MRZ_BULK_MIN
+#define MRZ_BULK_MIN 96              // leading lanes worth a workgroup-wide bulk commit
+#endif
 #define MRZ_OFF_BITS 40
 #define MRZ_OFF_MASK ((1ull << MRZ_OFF_BITS) - 1)
 
@@ -52,7 +56,11 @@ struct mrz_chunk4 {
 struct mrz_wide_lds {
     mrz_lead Lp;          // the leader's state, published by wave 0 before a wide step
     int ctl[16];          // control words between wave 0 and the others
-    int64_t res64[4];     // long-match resolution of one lane: len, off, rev, (hits << 32 | misses)
+    int cmd;              // bumped by wave 0 for every command; the other waves wait on it
+    int nb, total;        // lanes of the prepared batch; candidates in its bitmap window
+    int bulk_y, bulk_a1, bulk_a2, bulk_end;  // bulk commit done by the preparation: lanes [0, bulk_y), scan totals
+    int64_t cw_base, w_end, floor_prep;
+    int cw_len;
     // formation
     int pref[MRZ_W];
     mrz_u64 word[MRZ_W];
@@ -65,11 +73,14 @@ struct mrz_wide_lds {
     int nw_cnt;                      // writes of overlay-walked lanes: slots other lanes have to re-check
     int nw_slot[MRZ_NW_MAX];
     unsigned short nw_lane[MRZ_NW_MAX];
-    int A1[MRZ_W];                 // inclusive scan: delta | evictions << 10 | inserts << 20
-    unsigned long long A2[MRZ_W];  // inclusive scan: culls | hits << 16 | misses << 32
-    unsigned long long fkey[MRZ_W];
-    int64_t boff[MRZ_W];
+    // what the committing wave needs of every lane (written by the lane's own thread at the end of the preparation)
+    int64_t blen[MRZ_W], boff[MRZ_W];  // best match of the lane's entries under the last_match of the preparation
     int brev[MRZ_W];
+    unsigned short bhm[MRZ_W];         // tag_hits << 8 | tag_misses of that look-up
+    unsigned short dep0[MRZ_W], dep1[MRZ_W];  // lanes whose speculated writes an overlay walk has assumed (MRZ_W: none)
+    unsigned char exec[MRZ_W];         // 0 not yet, 1 committed as prepared, 2 dropped / went through the cooperative path
+    int xw_n;                          // slots written by cooperative hand-overs inside this batch
+    int xw_slot[MRZ_XW_MAX];
     int pbase[MRZ_W];
     unsigned short chunk_id[MRZ_W][4];
     unsigned short pair_owner[MRZ_PAIR_MAX];
@@ -79,6 +90,7 @@ struct mrz_wide_lds {
     unsigned short bh_lane[MRZ_BH_SIZE][MRZ_BH_WRITERS];
     mrz_u64 cw[MRZ_CW_WORDS];
     int cwcum[MRZ_CW_WORDS + 1];
+    int cw_list[MRZ_W];   // slot of the r-th failing entry of the window, r < min(cwcum[last], MRZ_W)
     int wt1[MRZ_SEQ_WAVES], wt3[MRZ_SEQ_WAVES], wt5[MRZ_SEQ_WAVES];
     unsigned long long wt2[MRZ_SEQ_WAVES], wt4[MRZ_SEQ_WAVES];
     int wmin[4][MRZ_SEQ_WAVES];
@@ -86,16 +98,29 @@ struct mrz_wide_lds {
     mrz_coop_lds coop;
 };
 
-enum { MRZ_CTL_MODE, MRZ_CTL_WIDTH, MRZ_CTL_STOPKIND, MRZ_CTL_OK, MRZ_CTL_LONGSEEN };
+enum { MRZ_CTL_MODE, MRZ_CTL_WIDTH };
 
 // ---- workgroup-wide scans (all threads; one barrier each; `wt` must not be reused before another barrier) ----
+template <int NW>
+__device__ __forceinline__ void mrz_prep_sync() {
+    if (NW == 1)
+        MRZ_WAVE_SYNC();
+    else
+        __syncthreads();
+}
+
+template <int NW>
 __device__ __forceinline__ int mrz_wide_incl(int v, int *wt, int lane, int wave, int *total) {
     const int incl = mrz_wave_incl_sum(v, lane);
+    if (NW == 1) {
+        *total = mrz_lane_read(incl, 63);
+        return incl;
+    }
     if (lane == 63) wt[wave] = incl;
     __syncthreads();
     int add = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < MRZ_SEQ_WAVES; w++) {
+    for (int w = 0; w < NW; w++) {
         const int x = wt[w];
         tot += x;
         if (w < wave) add += x;
@@ -145,14 +170,15 @@ __device__ __forceinline__ int mrz_wide_min_read(const int *wm) {
     return r;
 }
 
-#ifdef MRZ_SEQ_STATS
-// diagnostics: number of threads of the workgroup for which `flag` holds (all threads call; one barrier)
+#ifdef MRZ_SEQ_COUNTS
+// diagnostics: number of threads of the workgroup for which `flag` holds (all threads call; two barriers each, so
+// these only exist in -DMRZ_SEQ_COUNTS builds and not in the timing build)
 #define ST_COUNT(k, flag)                                                                           \
     do {                                                                                            \
         const mrz_u64 m__ = __ballot(flag);                                                         \
         int t__;                                                                                    \
-        (void)mrz_wide_incl(lane == 0 ? __popcll(m__) : 0, S->wt5, lane, wave, &t__);               \
-        __syncthreads();                                                                            \
+        (void)mrz_wide_incl<NW>(lane == 0 ? __popcll(m__) : 0, S->wt5, lane, wave, &t__);           \
+        mrz_prep_sync<NW>();                                                                            \
         ST_ADD(k, t__);                                                                             \
     } while (0)
 #else
@@ -698,7 +724,7 @@ __device__ static void mrz_lane_best(const mrz_wide_lds *S, int gl, int nsame, i
 }
 
 // slot of the failing entry of rank `r` in the cull window
-__device__ __forceinline__ int mrz_cw_slot(const mrz_wide_lds *S, int64_t cw_base, int r) {
+__device__ __forceinline__ int mrz_cw_slot_search(const mrz_wide_lds *S, int64_t cw_base, int r) {
     int lo = 0, hi = MRZ_CW_WORDS - 1;
 #pragma unroll
     for (int it = 0; it < 5; it++) {
@@ -711,6 +737,11 @@ __device__ __forceinline__ int mrz_cw_slot(const mrz_wide_lds *S, int64_t cw_bas
     return (int)(cw_base + lo * 64 + mrz_select64(S->cw[lo], r - S->cwcum[lo]));
 }
 
+// the same from the list the preparation has laid out (ranks beyond it: the search)
+__device__ __forceinline__ int mrz_cw_slot(const mrz_wide_lds *S, int64_t cw_base, int r) {
+    return r < MRZ_W ? S->cw_list[r] : mrz_cw_slot_search(S, cw_base, r);
+}
+
 struct mrz_wide_ret {
     int used;        // candidates committed by this step
     bool coop_next;  // the next candidate (the first after L.p) has to go through the cooperative path
@@ -719,20 +750,26 @@ struct mrz_wide_ret {
     bool skipped_out;  // an emitted match ended beyond the batch
 };
 
-// One wide batch.  All threads of the workgroup call it with identical L, width; every wave returns the same L.
-__device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds *S, const int64_t *__restrict__ tags,
+// lane flags published for the committing wave
+#define MRZ_LF_CONF 1
+#define MRZ_LF_CPLX 2
+#define MRZ_LF_ACT 4
+#define MRZ_LF_INS 8
+#define MRZ_LF_LONG 16
+#define MRZ_LF_REVS 32   // some entry has equal bytes before it: its result depends on how close last_match is
+
+// PREPARATION of one wide batch (phases A-C): all threads of the workgroup, identical L (read only) and width.
+// Leaves everything the commit needs in LDS; S->nb == 0 means the bitmap window held no candidate.
+template <int NW>
+__device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wide_lds *S, const int64_t *__restrict__ tags,
                                      const mrz_u64 *__restrict__ bitmap, int64_t seg_start, int64_t lim, int64_t nwords,
-                                     int width, int tid, int lane, int wave, int64_t *stat, mrz_wide_ret *ret) {
+                                     int width, int tid, int lane, int wave, int64_t *stat) {
+    constexpr int WT = 64 * NW;  // threads (= lanes of the batch at most) taking part
     const uint8_t *__restrict__ buf = C.buf;
     mrz_slot *tab = C.tab;
     const int smask = (int)C.slot_mask;
     const int max_chain = (int)C.max_chain;
     const int64_t better = (L.min_mask << 1) | 1;
-    ret->used = 0;
-    ret->coop_next = false;
-    ret->ok = true;
-    ret->long_seen = false;
-    ret->skipped_out = false;
     PROF_T0();
 
     // ---- A: formation ----------------------------------------------------------------------------------
@@ -752,14 +789,16 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
             w = keepbits <= 0 ? 0ull : (w & mrz_low_mask((int)keepbits));
         }
     }
-    for (int i = tid; i < MRZ_BH_SIZE; i += MRZ_W) {
+    for (int i = tid; i < MRZ_BH_SIZE; i += WT) {
         S->bh_key[i] = 0u;
         S->bh_cnt[i] = 0u;
     }
     if (tid == 0) {
         S->pool_top = 0;
         S->nw_cnt = 0;
+        S->xw_n = 0;
     }
+    S->exec[tid] = 0;
     S->nchunk[tid] = 0;
     S->supp_w[tid] = (unsigned short)MRZ_W;
     S->supp_w2[tid] = (unsigned short)MRZ_W;
@@ -768,8 +807,8 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
     const bool want_cw = L.count + width > C.limit;
     const int cw_len = want_cw ? MRZ_CW_WORDS * 64 : 0;
     if (want_cw) {
-        for (int b = 0; b < MRZ_CW_WORDS / MRZ_SEQ_WAVES; b++) {
-            const int wi = b * MRZ_SEQ_WAVES + wave;
+        for (int b = 0; b < MRZ_CW_WORDS / NW; b++) {
+            const int wi = b * NW + wave;
             const int64_t slot = cw_base + (int64_t)wi * 64 + lane;
             mrz_slot e;
             e.off = 0;
@@ -782,10 +821,10 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
         S->cw[tid] = 0ull;
     const int cnt = __popcll(w);
     int total;
-    const int incl = mrz_wide_incl(cnt, S->wt1, lane, wave, &total);
+    const int incl = mrz_wide_incl<NW>(cnt, S->wt1, lane, wave, &total);
     S->pref[tid] = incl - cnt;
     S->word[tid] = w;
-    __syncthreads();
+    mrz_prep_sync<NW>();
     if (wave == 0) {
         const int c = lane < MRZ_CW_WORDS ? __popcll(S->cw[lane]) : 0;
         const int ci = mrz_wave_incl_sum(c, lane);
@@ -793,17 +832,27 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
         if (lane == 0) S->cwcum[0] = 0;
     }
     const int nb = total < width ? total : width;
+    if (tid == 0) {
+        const int64_t wend = seg_start + (w0 + WT) * 64 - 1;
+        S->nb = nb;
+        S->total = total;
+        S->cw_base = cw_base;
+        S->cw_len = cw_len;
+        S->w_end = wend < lim ? wend : lim;
+        S->floor_prep = L.last_match > 0 ? L.last_match : 0;
+    }
     if (nb == 0) {
-        const int64_t wend = seg_start + (w0 + MRZ_W) * 64 - 1;
-        L.p = wend < lim ? wend : lim;
-        __syncthreads();
+        mrz_prep_sync<NW>();
         return;
     }
     const bool have = tid < nb;
+    mrz_prep_sync<NW>();  // cwcum is complete
+    for (int r = tid; r < MRZ_W; r += WT)
+        if (r < S->cwcum[MRZ_CW_WORDS]) S->cw_list[r] = mrz_cw_slot_search(S, cw_base, r);
     int64_t q = 0, t = 0;
     {
-        int wlo = 0, whi = MRZ_W - 1;
-        for (int it = 0; (1 << it) < MRZ_W; it++) {
+        int wlo = 0, whi = WT - 1;
+        for (int it = 0; (1 << it) < WT; it++) {
             const int mid = (wlo + whi + 1) >> 1;
             if (S->pref[mid] <= tid)
                 wlo = mid;
@@ -882,7 +931,7 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
         }
     }
     PROF_ADD(MRZ_ST_T_WALK);
-    __syncthreads();
+    mrz_prep_sync<NW>();
     int wr[2] = { -1, -1 };
     int nwr = 0;
     if (act && !cplx) {
@@ -897,7 +946,7 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
     {
         const bool win_stale = act && !cplx && conf && nwr == 0;  // stale only because of the cull window
         S->lf[tid] = (unsigned char)((conf ? 1 : 0) | (cplx ? 2 : 0) | (act ? 4 : 0));
-        __syncthreads();
+        mrz_prep_sync<NW>();
         bool elig = act && !cplx && conf && !win_stale && nwr >= 1 && nwr <= 2;
         int cwhy = 0;  // why a stale lane could not be repaired here (diagnostics)
         if (act && !cplx && conf && !elig) cwhy = win_stale ? 1 : 4;
@@ -950,7 +999,7 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
         }
         const mrz_u64 m_el = __ballot(elig);
         int n_el;
-        (void)mrz_wide_incl(lane == 0 ? __popcll(m_el) : 0, S->wt5, lane, wave, &n_el);
+        (void)mrz_wide_incl<NW>(lane == 0 ? __popcll(m_el) : 0, S->wt5, lane, wave, &n_el);
         if (n_el) {  // uniform
             ST_ADD(MRZ_ST_OVL, n_el);
             mrz_wl wn;
@@ -1031,7 +1080,7 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
                 // a lane whose overlay walk failed keeps the facts of its first walk published: they are what the
                 // lanes behind it were checked against, and it walks again when its turn comes
             }
-            __syncthreads();
+            mrz_prep_sync<NW>();
             // every lane whose walk stands looks at the new writes of the overlay lanes before it
             int nw = S->nw_cnt;
             if (nw > MRZ_NW_MAX) nw = MRZ_NW_MAX;
@@ -1050,7 +1099,7 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
             {
                 const mrz_u64 mg = __ballot(elig && good && !conf);
                 int tg;
-                (void)mrz_wide_incl(lane == 0 ? __popcll(mg) : 0, S->wt3, lane, wave, &tg);
+                (void)mrz_wide_incl<NW>(lane == 0 ? __popcll(mg) : 0, S->wt3, lane, wave, &tg);
                 ST_ADD(MRZ_ST_OVL_OK, tg);
             }
 #endif
@@ -1063,25 +1112,25 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
         ST_COUNT(MRZ_ST_C_TIE, conf && cwhy == 6);
         ST_COUNT(MRZ_ST_C_NW, conf && cwhy == 7);
     }
-    PROF_ADD(MRZ_ST_T_REWALK);
+    PROF_ADD(MRZ_ST_T_OVL);
 
     // ---- C: pairs (lanes whose walk stands) ----------------------------------------------------------------
     auto do_pairs = [&](bool need) {
         const int ns = need ? (wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX) : 0;
         int P;
-        const int pincl = mrz_wide_incl(ns, S->wt3, lane, wave, &P);
+        const int pincl = mrz_wide_incl<NW>(ns, S->wt3, lane, wave, &P);
         const int pb = pincl - ns;
         S->pbase[tid] = pb;
         for (int k = 0; k < ns; k++) S->pair_owner[pb + k] = (unsigned short)tid;
-        __syncthreads();
-        for (int i = tid; i < P; i += MRZ_W) {
+        mrz_prep_sync<NW>();
+        for (int i = tid; i < P; i += WT) {
             const int o = S->pair_owner[i];
             const int k = i - S->pbase[o];
             const int c = S->chunk_id[o][k >> 2];
             const int64_t op = (int64_t)(S->pool[c].e[k & 3] & MRZ_OFF_MASK);
             S->pool[c].raw[k & 3] = (unsigned short)mrz_lane_probe_raw(buf, S->q[o], op, C.end);
         }
-        __syncthreads();
+        mrz_prep_sync<NW>();
     };
     do_pairs(act && !cplx && !conf);
     PROF_ADD(MRZ_ST_T_PAIRS);
@@ -1091,69 +1140,270 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
     {
         const mrz_u64 mc = __ballot(conf);
         int tc;
-        const int ic = mrz_wide_incl(lane == 0 ? __popcll(mc) : 0, S->wt5, lane, wave, &tc);
+        const int ic = mrz_wide_incl<NW>(lane == 0 ? __popcll(mc) : 0, S->wt5, lane, wave, &tc);
         (void)ic;
         ST_ADD(MRZ_ST_CONF0, tc);
     }
 #endif
 
-    // ---- E: commit in segments ---------------------------------------------------------------------------
-    int64_t cb_len = 0, cb_off = 0, cb_floor = -1;
-    int cb_rev = 0, cb_h = 0, cb_m = 0;
-    bool cb_have = false, cb_long = false, cb_resolved = false;
+    // ---- what the committing wave needs of this lane ------------------------------------------------------------
+    {
+        const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
+        int64_t bl = 0, bo = 0;
+        int br = 0, bh = 0, bm = 0;
+        bool lng = false;
+        if (act && !cplx && !conf)
+            mrz_lane_best(S, tid, wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX, q, floor_p, &bl, &bo, &br, &bh, &bm, &lng);
+        S->blen[tid] = bl;
+        S->boff[tid] = bo;
+        S->brev[tid] = br;
+        S->bhm[tid] = (unsigned short)((bh << 8) | bm);
+        S->dep0[tid] = (unsigned short)(dep0 >= 0 ? dep0 : MRZ_W);
+        S->dep1[tid] = (unsigned short)(dep1 >= 0 ? dep1 : MRZ_W);
+        S->len1[tid] = (act && !cplx) ? len1 : 0;
+        S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
+        bool revs = false;
+        if (act && !cplx && !conf) {
+            const int nsx = wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX;
+            for (int k = 0; k < nsx; k++) revs = revs || ((S->pool[S->chunk_id[tid][k >> 2]].raw[k & 3] >> 8) & 127) != 0;
+        }
+        S->lf[tid] = (unsigned char)((conf ? MRZ_LF_CONF : 0) | (cplx ? MRZ_LF_CPLX : 0) | (act ? MRZ_LF_ACT : 0) |
+                                     (ins ? MRZ_LF_INS : 0) | (lng ? MRZ_LF_LONG : 0) | (revs ? MRZ_LF_REVS : 0));
+
+        // ---- E0: bulk commit.  The leading lanes up to the first one that is stale, complex or has a match to fold
+        // need none of the lazy-match logic (no match can be adopted or emitted among them when none is pending):
+        // all waves commit them at once -- scans for victim_round, hash_count and the cull ranks as in the commit
+        // proper -- and hand wave 0 the totals.  Match-free stretches (noise) are committed entirely here.
+        const bool stopish = have && act && (cplx || conf || lng || bl > 0);
+        {
+            const int f = mrz_wave_first(stopish, wave, nb);
+            if (lane == 0) S->wmin[0][wave] = f;
+        }
+        mrz_prep_sync<NW>();
+        int x0 = S->wmin[0][0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) x0 = S->wmin[0][w] < x0 ? S->wmin[0][w] : x0;
+        if (L.cur_len >= MRZ_MIN_MATCH) x0 = 0;  // a pending match may be emitted at any lane
+        if (x0 >= MRZ_BULK_MIN) {
+            const bool inb = tid < x0;
+            const bool a_ins = inb && ins;
+            const bool a_ev = a_ins && wl.kind == 3;
+            const int d = a_ins ? (wl.kind == 0 ? 1 : (wl.kind == 2 ? (wl.kind2 == 0 ? 1 : 0) : 0)) : 0;
+            int dummy;
+            const int i1 = mrz_wide_incl<NW>(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wt1, lane, wave, &dummy);
+            int wslot = wl.wslot;
+            if (a_ev) {
+                const int er = ((i1 >> 10) & 1023) - 1;
+                const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
+                wslot = (int)(mrz_pool_get(S, tid, vr) >> MRZ_OFF_BITS);
+            }
+            int64_t c_before = L.count + ((i1 & 1023) - d);
+            if (c_before > C.limit) c_before = C.limit;
+            const bool cull = a_ins && (c_before + d > C.limit);
+            const int i2 = mrz_wide_incl<NW>((cull ? 1 : 0) | ((inb && act ? bm : 0) << 10), S->wt3, lane, wave, &dummy);
+            int cslot = -1;
+            bool overflow = false;
+            if (cull) {
+                const int cr = (i2 & 1023) - 1;
+                if (cr >= S->cwcum[MRZ_CW_WORDS])
+                    overflow = true;
+                else
+                    cslot = mrz_cw_slot(S, cw_base, cr);
+            }
+            {
+                const int fo_ = mrz_wave_first(overflow, wave, MRZ_W);
+                const int fc_ = mrz_wave_first(cull, wave, MRZ_W);
+                if (lane == 0) {
+                    S->wmin[1][wave] = fo_;
+                    S->wmin[2][wave] = fc_;
+                }
+            }
+            mrz_prep_sync<NW>();
+            int o_lane = S->wmin[1][0], c_lane = S->wmin[2][0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) {
+                o_lane = S->wmin[1][w] < o_lane ? S->wmin[1][w] : o_lane;
+                c_lane = S->wmin[2][w] < c_lane ? S->wmin[2][w] : c_lane;
+            }
+            int y = x0;
+            bool endb = false;
+            if (o_lane < y) {
+                y = o_lane;
+                endb = true;
+            }
+            if (loose && c_lane + 1 <= y) {  // the first cull ever switches the insert mask (:583)
+                y = c_lane + 1;
+                endb = true;
+            }
+            if (tid < y) {
+                if (a_ins) {
+                    if (wl.kind == 2 && S->supp_w2[tid] >= y) {
+                        mrz_slot oc;
+                        oc.off = wl.occ_off;
+                        oc.t = wl.occ_t;
+                        tab[wl.w2] = oc;
+                    }
+                    if (S->supp_w[tid] >= y) {
+                        mrz_slot nw;
+                        nw.off = q;
+                        nw.t = t;
+                        tab[wslot] = nw;
+                    }
+                    if (cslot >= 0) {
+                        mrz_slot z;
+                        z.off = 0;
+                        z.t = 0;
+                        tab[cslot] = z;
+                    }
+                }
+                S->exec[tid] = 1;
+            }
+            if (y > 0 && tid == y - 1) {
+                S->bulk_a1 = i1;
+                S->bulk_a2 = i2;
+            }
+            if (tid == 0) {
+                S->bulk_y = y;
+                S->bulk_end = endb ? 1 : 0;
+            }
+        } else if (tid == 0)
+            S->bulk_y = 0;
+    }
+    mrz_prep_sync<NW>();
+}
+
+// COMMIT of a prepared batch (phase E): wave 0 alone, no workgroup barrier.  Windows of up to 64 lanes starting at the
+// first lane not yet dealt with; a window is cut at the first lane that cannot be committed as prepared.
+__device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds *S, int lane, int64_t *stat,
+                                       mrz_wide_ret *ret) {
+    mrz_slot *tab = C.tab;
+    const int smask = (int)C.slot_mask;
+    const int max_chain = (int)C.max_chain;
+    const int64_t better = (L.min_mask << 1) | 1;
+    const bool loose = L.tag_mask != better;
+    const int nb = mrz_uni(S->nb), total = mrz_uni(S->total);
+    const int64_t cw_base = mrz_uni64(S->cw_base);
+    const int cw_len = mrz_uni(S->cw_len);
+    const int64_t floor_prep = mrz_uni64(S->floor_prep);
+    ret->used = 0;
+    ret->coop_next = false;
+    ret->ok = true;
+    ret->long_seen = false;
+    ret->skipped_out = false;
+    PROF_T0();
+    if (nb == 0) {
+        const int64_t we = mrz_uni64(S->w_end);
+        if (we > L.p) L.p = we;
+        return;
+    }
     int s = 0, cw_used = 0, committed = 0, iters = 0;
-    while (true) {
+    bool bulk_end = false;
+    {
+        // what the preparation has committed in bulk already: lanes [0, y)
+        const int y = mrz_uni(S->bulk_y);
+        if (y > 0) {
+            const int a1 = mrz_uni(S->bulk_a1), a2 = mrz_uni(S->bulk_a2);
+            const int dsum = a1 & 1023, esum = (a1 >> 10) & 1023, isum = (a1 >> 20) & 1023;
+            const int csum = a2 & 1023, msum = a2 >> 10;
+            L.inserts += isum;
+            int64_t cnew = L.count + dsum;
+            if (cnew > C.limit) cnew = C.limit;
+            L.count = cnew;
+            if (csum) {
+                L.clean_ptr = mrz_cw_slot(S, cw_base, csum - 1);
+                L.tag_mask = better;
+                cw_used = csum;
+            }
+            if (esum) L.victim_round = (int64_t)(((unsigned)L.victim_round + (unsigned)esum) % (unsigned)max_chain);
+            L.tag_misses += msum;
+            L.p = mrz_uni64(S->q[y - 1]);
+            committed = y;
+            s = y;
+            bulk_end = mrz_uni(S->bulk_end) != 0;
+            ST_ADD(MRZ_ST_SEGMENTS, 1);
+        }
+    }
+    // a lane resolved by the long-match path: its exact result, valid for the last_match it was measured under
+    int res_lane = -1;
+    int64_t res_len = 0, res_off = 0, res_floor = -1;
+    int res_rev = 0, res_h = 0, res_m = 0;
+    while (s < nb && !bulk_end) {
         if (++iters > 8 * MRZ_W) {  // cannot happen: every iteration commits, drops or repairs a lane
-            if (tid == 0) C.st->error = 3;
+            if (lane == 0) C.st->error = 3;
             ret->ok = false;
             break;
         }
         const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
-        const bool inb = have && tid >= s;
-        if (inb && act && !cplx && !conf) {
-            if (!cb_have || (floor_p != cb_floor && (cb_resolved || q - floor_p <= 64))) {
-                mrz_lane_best(S, tid, wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX, q, floor_p, &cb_len, &cb_off, &cb_rev, &cb_h,
-                              &cb_m, &cb_long);
-                cb_have = true;
-                cb_resolved = false;
-                cb_floor = floor_p;
-                S->boff[tid] = cb_off;
-                S->brev[tid] = cb_rev;
+        const int i = s + lane;
+        const bool have = i < nb;
+        const int ii = have ? i : nb - 1;
+        const int f = have ? S->lf[ii] : 0;
+        const bool act = (f & MRZ_LF_ACT) != 0, ins = (f & MRZ_LF_INS) != 0, cplx = (f & MRZ_LF_CPLX) != 0;
+        bool conf = (f & MRZ_LF_CONF) != 0;
+        const int64_t q = S->q[ii];
+        // late staleness: a lane whose speculated writes this lane had laid over its walk did not commit them, or a
+        // cooperative hand-over inside this batch wrote into what it has read
+        if (have && act && !cplx && !conf) {
+            // (a lane of this very window either commits together with this one or cuts the segment before it)
+            const int d0 = S->dep0[ii], d1 = S->dep1[ii];
+            if ((d0 < s && S->exec[d0] != 1) || (d1 < s && S->exec[d1] != 1)) conf = true;
+            const int nx = S->xw_n;
+            if (nx > 0) {
+                const int h = S->h[ii], len1 = S->len1[ii], h2 = S->h2[ii], len2 = S->len2[ii];
+                for (int k = 0; k < nx && !conf; k++) {
+                    const int sl = S->xw_slot[k];
+                    if ((len1 > 0 && mrz_in_range(sl, h, len1, smask)) || (len2 > 0 && mrz_in_range(sl, h2, len2, smask)))
+                        conf = true;
+                }
             }
         }
-        const bool stop = inb && act && (cplx || conf || cb_long);
-        {
-            const int f = mrz_wave_first(stop, wave, nb);
-            if (lane == 0) S->wmin[0][wave] = f;
+        // the lane's best match under the current last_match
+        int64_t blen = 0, boff = 0;
+        int brev = 0, bh = 0, bm = 0;
+        bool lng = false;
+        if (have && act && !cplx && !conf) {
+            if (i == res_lane && floor_p == res_floor) {
+                blen = res_len;
+                boff = res_off;
+                brev = res_rev;
+                bh = res_h;
+                bm = res_m;
+            } else if ((f & MRZ_LF_REVS) && (q - floor_p <= 64 || (floor_p != floor_prep && q - floor_prep <= 64))) {
+                mrz_lane_best(S, ii, S->ns[ii], q, floor_p, &blen, &boff, &brev, &bh, &bm, &lng);
+            } else {
+                blen = S->blen[ii];
+                boff = S->boff[ii];
+                brev = S->brev[ii];
+                const int hm = S->bhm[ii];
+                bh = hm >> 8;
+                bm = hm & 255;
+                lng = (f & MRZ_LF_LONG) != 0;
+            }
         }
-        __syncthreads();
-        const int x = mrz_wide_min_read(S->wmin[0]);
-        if (x == s) {
-            // ---- the stop lane is next: bring it into a committable state, or hand it to the cooperative path
-            if (tid == x) S->ctl[MRZ_CTL_STOPKIND] = cplx ? 1 : (conf ? 2 : 3);
-            __syncthreads();
-            const int sk = S->ctl[MRZ_CTL_STOPKIND];
-            if (sk == 1 || sk == 2) {
-                // A lane the batch cannot vouch for -- stale (an earlier lane wrote into what it read) or beyond the
-                // per-lane walk (long chain, deep cascade) -- goes through the cooperative path right here: wave 0
-                // replays this one candidate in full against the table as committed so far, the batch goes on behind it.
-                ST_ADD(sk == 1 ? MRZ_ST_CUT_CPLX : MRZ_ST_REWALK, 1);
+        const bool stop = have && act && (cplx || conf || lng);
+        const mrz_u64 m_stop = __ballot(stop);
+        int nseg = nb - s < 64 ? nb - s : 64;
+        if (m_stop) nseg = __ffsll((long long)m_stop) - 1;
+        if (nseg == 0) {
+            // ---- lane s cannot be committed as prepared ---------------------------------------------------------
+            const bool s_cplx = mrz_lane_read((int)cplx, 0) != 0, s_conf = mrz_lane_read((int)conf, 0) != 0;
+            if (s_cplx || s_conf) {
+                // stale (an earlier lane wrote into what it read) or beyond the per-lane walk (long chain, deep
+                // cascade): the cooperative path replays this one candidate in full against the table as committed
+                // so far; the batch goes on behind it
+                ST_ADD(s_cplx ? MRZ_ST_CUT_CPLX : MRZ_ST_REWALK, 1);
+                PROF_ADD(MRZ_ST_H_PRE);
                 const int64_t pre_min = L.min_mask, pre_tag = L.tag_mask, pre_events = L.n_events;
-                if (wave == 0) {
-                    L.p = S->q[x];
-                    const bool okc = mrz_seq_candidate(C, L, &S->coop, S->t[x], lane, stat);
-                    if (lane == 0) {
-                        S->Lp = L;
-                        S->ctl[MRZ_CTL_OK] = okc ? 1 : 0;
-                    }
-                }
-                __syncthreads();
-                L = S->Lp;
+                const int64_t q_e = mrz_uni64(S->q[s]);
+                L.p = q_e;
+                const bool okc = mrz_seq_candidate(C, L, &S->coop, mrz_uni64(S->t[s]), lane, stat);
+                PROF_ADD(MRZ_ST_H_CAND);
                 committed += 1;
-                if (!mrz_uni(S->ctl[MRZ_CTL_OK])) {
+                if (!okc) {
                     ret->ok = false;
                     break;
                 }
+                if (lane == 0) S->exec[s] = 2;
                 const int nwx = mrz_uni(S->coop.n_written);
                 const int64_t cullx = mrz_uni64(S->coop.cull_slot);
                 bool stop_batch = L.min_mask != pre_min || L.tag_mask != pre_tag;
@@ -1164,165 +1414,133 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
                     else
                         cw_used++;
                 }
-                for (int k = 0; k < nwx; k++) {
-                    const int64_t hs = S->coop.pend_h[k];
-                    if (cw_len > 0 && hs >= cw_base && hs < cw_base + cw_len) stop_batch = true;
-                }
-                // its writes against the reads of the lanes behind it; lanes that had laid its speculated writes over
-                // their walk are stale as well
-                if (have && tid > x && act && !cplx && !conf) {
-                    if (dep0 == x || dep1 == x) conf = true;
-                    for (int k = 0; k < nwx && !conf; k++) {
-                        const int hs = (int)S->coop.pend_h[k];
-                        if ((len1 > 0 && mrz_in_range(hs, h, len1, smask)) || (wl.len2 > 0 && mrz_in_range(hs, wl.h2, wl.len2, smask)))
-                            conf = true;
+                int nx = mrz_uni(S->xw_n);
+                if (nx + nwx + 1 > MRZ_XW_MAX)
+                    stop_batch = true;
+                else {
+                    // its writes: the lanes behind it look at them when their window comes up
+                    if (lane < nwx) {
+                        const int64_t hs = S->coop.pend_h[lane];
+                        S->xw_slot[nx + lane] = (int)hs;
                     }
-                    if (cullx >= 0 && ((len1 > 0 && mrz_in_range((int)cullx, h, len1, smask)) ||
-                                       (wl.len2 > 0 && mrz_in_range((int)cullx, wl.h2, wl.len2, smask))))
-                        conf = true;
+                    if (cullx >= 0 && lane == 0) S->xw_slot[nx + nwx] = (int)cullx;
+                    const bool inwin = lane < nwx && cw_len > 0 && S->coop.pend_h[lane] >= cw_base &&
+                                       S->coop.pend_h[lane] < cw_base + cw_len;
+                    if (__ballot(inwin)) stop_batch = true;
+                    nx += nwx + (cullx >= 0 ? 1 : 0);
+                    if (lane == 0) S->xw_n = nx;
                 }
-                int s_next = x + 1;
+                MRZ_WAVE_SYNC();
+                int s_next = s + 1;
                 if (L.n_events != pre_events) {
                     ST_ADD(MRZ_ST_EMITS, 1);
-                    const int64_t q_e = S->q[x];
                     if (L.last_match >= q_e) {
-                        int lo = x + 1, hi = nb;
+                        int lo = s + 1, hi = nb;
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
-                            if (S->q[mid] > L.last_match)
+                            if (mrz_uni64(S->q[mid]) > L.last_match)
                                 hi = mid;
                             else
                                 lo = mid + 1;
                         }
                         s_next = lo;
+                        for (int k = s + 1 + lane; k < s_next; k += 64) S->exec[k] = 2;  // dropped
                         if (s_next >= nb) {
                             ret->skipped_out = true;
                             ST_ADD(MRZ_ST_SKIPOUT, 1);
                         }
                     } else {
                         ST_ADD(MRZ_ST_BACKJUMP, 1);
-                        s_next = x;  // comes by q_e again, after its own insert: the cooperative path once more
-                        if (tid == x) conf = true;
+                        s_next = s;  // comes by q_e again, after its own insert: the cooperative path once more
+                        if (lane == 0) S->lf[s] = (unsigned char)(S->lf[s] | MRZ_LF_CONF);
                     }
-                    if (have && tid >= s_next && ((dep0 > x && dep0 < s_next) || (dep1 > x && dep1 < s_next))) conf = true;
-                }
-                s = s_next;
-                PROF_ADD(MRZ_ST_T_REWALK);
-                __syncthreads();
-                if (stop_batch || s >= nb) break;
-                continue;
-            }
-            // sk == 3: tag-equal entries beyond the 64-byte reach: wave 0 measures them exactly (striped rounds,
-            // compare farm) and folds the lane's entries in probe order
-            ST_ADD(MRZ_ST_LONGRES, 1);
-            ret->long_seen = true;
-            if (wave == 0) {
-                const int nsx = S->ns[x];
-                const int64_t qx = S->q[x];
-                if (lane < nsx) {
-                    const int c = S->chunk_id[x][lane >> 2];
-                    const unsigned long long v = S->pool[c].e[lane & 3];
-                    const int64_t op = (int64_t)(v & MRZ_OFF_MASK);
-                    int64_t ml;
-                    int rv;
-                    bool l;
-                    mrz_pair_eval(S->pool[c].raw[lane & 3], qx, op, floor_p, &ml, &rv, &l);
-                    S->coop.same_off[lane] = op;
-                    S->coop.pair_res[lane] = l ? -1 : (int)((ml << 8) | rv);
                 }
                 MRZ_WAVE_SYNC();
-                int64_t xb = 0, xoff = 0, xrev = 0;
-                int xh = 0, xm = 0;
-                mrz_resolve_entries(C, L, &S->coop, qx, nsx, lane, stat, &xb, &xoff, &xrev, &xh, &xm);
-                if (lane == 0) {
-                    S->res64[0] = xb;
-                    S->res64[1] = xoff;
-                    S->res64[2] = xrev;
-                    S->res64[3] = ((int64_t)xh << 32) | (int64_t)xm;
-                }
+                s = s_next;
+                PROF_ADD(MRZ_ST_H_POST);
+                if (stop_batch) break;
+                continue;
             }
-            __syncthreads();
-            if (tid == x) {
-                cb_len = S->res64[0];
-                cb_off = S->res64[1];
-                cb_rev = (int)S->res64[2];
-                cb_h = (int)(S->res64[3] >> 32);
-                cb_m = (int)(S->res64[3] & 0xffffffffll);
-                cb_long = false;
-                cb_have = true;
-                cb_resolved = true;
-                cb_floor = floor_p;
-                S->boff[tid] = cb_off;
-                S->brev[tid] = cb_rev;
+            // tag-equal entries beyond the 64-byte reach: measured exactly (striped rounds, compare farm) and folded
+            // in probe order
+            ST_ADD(MRZ_ST_LONGRES, 1);
+            ret->long_seen = true;
+            const int nsx = mrz_uni(S->ns[s]);
+            const int64_t qx = mrz_uni64(S->q[s]);
+            if (lane < nsx) {
+                const int c = S->chunk_id[s][lane >> 2];
+                const unsigned long long v = S->pool[c].e[lane & 3];
+                const int64_t op = (int64_t)(v & MRZ_OFF_MASK);
+                int64_t ml;
+                int rv;
+                bool l;
+                mrz_pair_eval(S->pool[c].raw[lane & 3], qx, op, floor_p, &ml, &rv, &l);
+                S->coop.same_off[lane] = op;
+                S->coop.pair_res[lane] = l ? -1 : (int)((ml << 8) | rv);
             }
+            MRZ_WAVE_SYNC();
+            int64_t xb = 0, xoff = 0, xrev = 0;
+            int xh = 0, xm = 0;
+            mrz_resolve_entries(C, L, &S->coop, qx, nsx, lane, stat, &xb, &xoff, &xrev, &xh, &xm);
+            res_lane = s;
+            res_len = xb;
+            res_off = xoff;
+            res_rev = (int)xrev;
+            res_h = xh;
+            res_m = xm;
+            res_floor = floor_p;
             PROF_ADD(MRZ_ST_T_LONG);
             continue;
         }
 
-        // ---- scans over the segment [s, x) -------------------------------------------------------------
+        // ---- the segment [s, s + nseg): sequential quantities by wave scans ----------------------------------------
         ST_ADD(MRZ_ST_SEGMENTS, 1);
-        const bool inseg = inb && tid < x;
-        const bool a_ins = inseg && ins;  // act, not cplx, not stale
-        const bool a_ev = a_ins && wl.kind == 3;
-        const int d = a_ins ? (wl.kind == 0 ? 1 : (wl.kind == 2 ? (wl.kind2 == 0 ? 1 : 0) : 0)) : 0;
-        int dummy;
-        const int i1 = mrz_wide_incl(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wt1, lane, wave, &dummy);
-        S->A1[tid] = i1;
-        int wslot = wl.wslot;
+        const bool inseg = lane < nseg;
+        const int kind = S->kind[ii], kind2 = S->kind2[ii];
+        const bool a_ins = inseg && ins && act;
+        const bool a_ev = a_ins && kind == 3;
+        const int d = a_ins ? (kind == 0 ? 1 : (kind == 2 ? (kind2 == 0 ? 1 : 0) : 0)) : 0;
+        const int i1 = mrz_wave_incl_sum(d | (a_ev ? 1 << 8 : 0) | (a_ins ? 1 << 16 : 0), lane);
+        int wslot = S->wslot[ii];
         if (a_ev) {
             // victim_round for evicting lanes (static victim_round, src/rzip.c:259,283-289)
-            const int er = ((i1 >> 10) & 1023) - 1;
+            const int er = ((i1 >> 8) & 255) - 1;
             const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
-            wslot = (int)(mrz_pool_get(S, tid, vr) >> MRZ_OFF_BITS);
+            wslot = (int)(mrz_pool_get(S, ii, vr) >> MRZ_OFF_BITS);
         }
         // hash_count before each lane: saturating prefix sum of the per-lane deltas
-        int64_t c_before = L.count + ((i1 & 1023) - d);
+        int64_t c_before = L.count + ((i1 & 255) - d);
         if (c_before > C.limit) c_before = C.limit;
         const bool cull = a_ins && (c_before + d > C.limit);
-        const mrz_u64 i2 = mrz_wide_incl64((cull ? 1ull : 0ull) | ((mrz_u64)((inseg && act) ? cb_h : 0) << 16) |
-                                               ((mrz_u64)((inseg && act) ? cb_m : 0) << 32),
-                                           S->wt2, lane, wave);
-        S->A2[tid] = i2;
+        const int i2 = mrz_wave_incl_sum((cull ? 1 : 0) | ((inseg && act ? bh : 0) << 8) | ((inseg && act ? bm : 0) << 20), lane);
         int cslot = -1;
         bool overflow = false;
         if (cull) {
-            const int cr = cw_used + (int)(i2 & 0xffffu) - 1;
+            const int cr = cw_used + (i2 & 255) - 1;
             if (cr >= S->cwcum[MRZ_CW_WORDS])
                 overflow = true;  // the sweep leaves the window (or wraps / promotes)
             else
                 cslot = mrz_cw_slot(S, cw_base, cr);
         }
         // ---- the lazy-match fold (src/rzip.c:586-599) as a prefix maximum: first longest wins ---------------
-        const int rel = tid - s + 1;
-        const mrz_u64 key = (inseg && act) ? (((mrz_u64)cb_len << 10) | (mrz_u64)(1023 - rel)) : 0ull;
-        mrz_u64 K = mrz_wide_inclmax64(key, S->wt4, lane, wave);
+        mrz_u64 K = mrz_wave_incl_max64((inseg && act) ? (((mrz_u64)blen << 7) | (mrz_u64)(127 - (lane + 1))) : 0ull, lane);
         {
-            const mrz_u64 k0 = ((mrz_u64)L.cur_len << 10) | 1023ull;
+            const mrz_u64 k0 = ((mrz_u64)L.cur_len << 7) | 127ull;
             if (k0 > K) K = k0;
         }
-        S->fkey[tid] = K;
-        bool emit = false;
-        if (inseg && act) {
-            const int64_t curlen = (int64_t)(K >> 10);
-            const int arel = 1023 - (int)(K & 1023ull);
-            const int64_t curp = arel == 0 ? L.cur_p : S->q[s + arel - 1] - S->brev[s + arel - 1];
-            emit = curlen >= MRZ_MIN_MATCH && (curlen >= MRZ_GREAT_MATCH || q >= curp + MRZ_MIN_MATCH);
-        }
-        {
-            const int fe_ = mrz_wave_first(emit, wave, MRZ_W);
-            const int fo_ = mrz_wave_first(overflow, wave, MRZ_W);
-            const int fc_ = mrz_wave_first(cull, wave, MRZ_W);
-            if (lane == 0) {
-                S->wmin[1][wave] = fe_;
-                S->wmin[2][wave] = fo_;
-                S->wmin[3][wave] = fc_;
-            }
-        }
-        __syncthreads();
-        const int e_lane = mrz_wide_min_read(S->wmin[1]);
-        const int o_lane = mrz_wide_min_read(S->wmin[2]);
-        const int c_lane = mrz_wide_min_read(S->wmin[3]);
-        int y = x;
+        const int arel = 127 - (int)(K & 127ull);  // 0: the match carried in; else lane arel - 1 of this window
+        const int64_t a_q = mrz_shfl64(q, arel > 0 ? arel - 1 : 0);
+        const int a_rev = __shfl(brev, arel > 0 ? arel - 1 : 0, MRZ_WAVE);
+        const int64_t a_off = mrz_shfl64(boff, arel > 0 ? arel - 1 : 0);
+        const int64_t curlen = (int64_t)(K >> 7);
+        const int64_t curp = arel == 0 ? L.cur_p : a_q - a_rev;
+        const int64_t curofs = arel == 0 ? L.cur_ofs : a_off;
+        const bool emit = inseg && act && curlen >= MRZ_MIN_MATCH && (curlen >= MRZ_GREAT_MATCH || q >= curp + MRZ_MIN_MATCH);
+        const mrz_u64 m_emit = __ballot(emit), m_over = __ballot(overflow), m_cull = __ballot(cull);
+        const int e_lane = m_emit ? __ffsll((long long)m_emit) - 1 : 64;
+        const int o_lane = m_over ? __ffsll((long long)m_over) - 1 : 64;
+        const int c_lane = m_cull ? __ffsll((long long)m_cull) - 1 : 64;
+        int y = nseg;  // lanes [0, y) of this window commit
         bool end_batch = false;
         if (o_lane < y) {
             y = o_lane;
@@ -1337,29 +1555,29 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
         if (e_lane + 1 <= y) {
             y = e_lane + 1;
             emission = true;
-            end_batch = false;
-            if (loose && c_lane + 1 <= y) end_batch = true;
+            end_batch = loose && c_lane + 1 <= y;
         }
-        if (y == s) {
+        if (y == 0) {
             // the very next lane cannot be served from the cull window: a fresh batch reloads it; if even a fresh
             // window has nothing (sweep wrap, mask promotion) the cooperative path takes the candidate
             if (s == 0 && cw_used == 0) ret->coop_next = true;
             ST_ADD(MRZ_ST_CUT_OVERFLOW, 1);
             break;
         }
+        PROF_ADD(MRZ_ST_T_SCAN);
 
-        // ---- commit [s, y) ---------------------------------------------------------------------------------
-        if (inseg && tid < y && ins) {
-            if (wl.kind == 2 && S->supp_w2[tid] >= y) {
+        // ---- commit lanes [0, y) of the window ----------------------------------------------------------------
+        if (lane < y && a_ins) {
+            if (kind == 2 && S->supp_w2[ii] >= s + y) {
                 mrz_slot oc;
-                oc.off = wl.occ_off;
-                oc.t = wl.occ_t;
-                tab[wl.w2] = oc;
+                oc.off = S->occ_off[ii];
+                oc.t = S->occ_t[ii];
+                tab[S->w2[ii]] = oc;
             }
-            if (S->supp_w[tid] >= y) {
+            if (S->supp_w[ii] >= s + y) {
                 mrz_slot nw;
                 nw.off = q;
-                nw.t = t;
+                nw.t = S->t[ii];
                 tab[wslot] = nw;
             }
             if (cslot >= 0) {
@@ -1369,11 +1587,11 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
                 tab[cslot] = z;
             }
         }
+        if (lane < y) S->exec[ii] = 1;
         {
-            const int a1 = S->A1[y - 1];
-            const mrz_u64 a2 = S->A2[y - 1];
-            const int dsum = a1 & 1023, esum = (a1 >> 10) & 1023, isum = (a1 >> 20) & 1023;
-            const int csum = (int)(a2 & 0xffffu), hsum = (int)((a2 >> 16) & 0xffffu), msum = (int)(a2 >> 32);
+            const int a1 = mrz_lane_read(i1, y - 1), a2 = mrz_lane_read(i2, y - 1);
+            const int dsum = a1 & 255, esum = (a1 >> 8) & 255, isum = (a1 >> 16) & 255;
+            const int csum = a2 & 255, hsum = (a2 >> 8) & 4095, msum = (a2 >> 20) & 4095;
             L.inserts += isum;
             int64_t cnew = L.count + dsum;
             if (cnew > C.limit) cnew = C.limit;
@@ -1386,28 +1604,22 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
             if (esum) L.victim_round = (int64_t)(((unsigned)L.victim_round + (unsigned)esum) % (unsigned)max_chain);
             L.tag_hits += hsum;
             L.tag_misses += msum;
-            const mrz_u64 Ky = S->fkey[y - 1];
-            const int arel = 1023 - (int)(Ky & 1023ull);
-            if (arel != 0) {
-                const int a = s + arel - 1;
-                L.cur_len = (int64_t)(Ky >> 10);
-                L.cur_p = S->q[a] - S->brev[a];
-                L.cur_ofs = S->boff[a];
-            }
-            L.p = S->q[y - 1];
-            committed += y - s;
+            L.cur_len = mrz_bcast64(curlen, y - 1);
+            L.cur_p = mrz_bcast64(curp, y - 1);
+            L.cur_ofs = mrz_bcast64(curofs, y - 1);
+            L.p = mrz_bcast64(q, y - 1);
+            committed += y;
         }
-        int s_next = y;
+        int s_next = s + y;
         if (emission) {
             ST_ADD(MRZ_ST_EMITS, 1);
             const int64_t q_e = L.p;
-            // the emission itself (put_literal / put_match happen in the encoder kernels)
             if (L.n_events >= C.event_cap) {  // cannot happen: matches are >= 31 bytes and disjoint
-                if (tid == 0) C.st->error = 1;
+                if (lane == 0) C.st->error = 1;
                 ret->ok = false;
                 break;
             }
-            if (tid == 0) {
+            if (lane == 0) {
                 mrz_event ev;
                 ev.p = L.cur_p;
                 ev.ofs = L.cur_ofs;
@@ -1421,15 +1633,16 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
             L.cur_len = 0;
             if (L.last_match >= q_e) {
                 // the lanes inside the match are dropped: first lane behind it
-                int lo = y, hi = nb;
+                int lo = s + y, hi = nb;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (S->q[mid] > L.last_match)
+                    if (mrz_uni64(S->q[mid]) > L.last_match)
                         hi = mid;
                     else
                         lo = mid + 1;
                 }
                 s_next = lo;
+                for (int k = s + y + lane; k < s_next; k += 64) S->exec[k] = 2;
                 if (s_next >= nb) {
                     ret->skipped_out = true;
                     ST_ADD(MRZ_ST_SKIPOUT, 1);
@@ -1438,30 +1651,23 @@ __device__ static void mrz_wide_step(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds
                 // the match ends before the emitting position: the loop goes BACK (p = last_match, :596) and comes
                 // by q_e again -- the only candidate of (last_match, q_e] -- after its own insert
                 ST_ADD(MRZ_ST_BACKJUMP, 1);
-                s_next = y - 1;
-                if (tid == y - 1) {
-                    conf = true;
-                    cb_have = false;
+                s_next = s + y - 1;
+                if (lane == 0) {
+                    S->lf[s_next] = (unsigned char)(S->lf[s_next] | MRZ_LF_CONF);
+                    S->exec[s_next] = 2;  // what it wrote stands, but lanes that assumed its writes read again
                 }
             }
         }
-        // lanes that had laid the writes of a dropped lane over their walk are stale
-        if (emission && have && tid >= s_next && (dep0 >= 0 || dep1 >= 0)) {
-            if ((dep0 >= y && dep0 < s_next) || (dep1 >= y && dep1 < s_next)) conf = true;
-        }
+        MRZ_WAVE_SYNC();
         s = s_next;
-        __syncthreads();  // the commits are in the table; the scan arrays may be reused
-        if (end_batch || s >= nb) break;
+        PROF_ADD(MRZ_ST_T_COMMIT);
+        if (end_batch) break;
     }
-    PROF_ADD(MRZ_ST_T_LOOP);
     // the window ran dry: skip its empty rest
-    if (!ret->coop_next && ret->ok && s >= nb && nb == total && L.p < seg_start + (w0 + MRZ_W) * 64 - 1 &&
-        L.last_match <= S->q[nb - 1]) {
-        const int64_t wend = seg_start + (w0 + MRZ_W) * 64 - 1;
-        const int64_t np = wend < lim ? wend : lim;
-        if (np > L.p) L.p = np;
+    if (ret->ok && !ret->coop_next && s >= nb && nb == total) {
+        const int64_t we = mrz_uni64(S->w_end);
+        if (we > L.p) L.p = we;
     }
     ST_ADD(MRZ_ST_COMMITTED, committed);
     ret->used = committed;
-    __syncthreads();
 }

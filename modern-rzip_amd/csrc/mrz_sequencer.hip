@@ -85,10 +85,34 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     const int64_t lim = (C.end < seg_end - 1) ? C.end : seg_end - 1;  // last candidate position of this launch
     const int64_t nwords = (a.seg_len + 63) / 64;
 
-    // wave 0 only: scheduling state
+#ifdef MRZ_SEQ_STATS
+    int64_t stat[MRZ_ST_N];
+    for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
+#else
+    int64_t *stat = nullptr;
+#endif
+    if (tid == 0) S->cmd = 0;
+    __syncthreads();
+
+    if (wave != 0) {
+        // ---- waves 1..: wait for wave 0's commands; a wide batch is prepared by all waves together ------------
+        int seen = 0;
+        while (true) {
+            int c;
+            while ((c = mrz_uni(mrz_mb_load(&S->cmd))) == seen) __builtin_amdgcn_s_sleep(2);
+            seen = c;
+            if (mrz_uni(S->ctl[MRZ_CTL_MODE]) == 0) return;
+            const mrz_lead Lw = S->Lp;
+            mrz_wide_prep<MRZ_SEQ_WAVES>(C, Lw, S, a.tags, a.bitmap, seg_start, lim, nwords, mrz_uni(S->ctl[MRZ_CTL_WIDTH]),
+                                         tid, lane, wave, stat);
+        }
+    }
+
+    // ---- wave 0: owns the matcher state, decides the mode, commits ------------------------------------------
     int64_t win_base = -1;
     mrz_u64 myword = 0;
     bool ok = true;
+    int cmd_seq = 0;
     int width = MRZ_W;         // batch width: small right after a match that swallowed the rest of a batch
     int low_yield = 0;         // consecutive batches that committed <= 2 candidates
     int seq_credit = 0;        // candidates to run through the cooperative path before batching again
@@ -101,76 +125,62 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     int pred_long[4] = { 0, 0, 0, 0 };
     int stall = 0;  // iterations without any progress (cannot happen; keeps a logic error from hanging the GPU)
     int64_t stall_p = L.p, stall_ev = L.n_events;
-#ifdef MRZ_SEQ_STATS
-    int64_t stat[MRZ_ST_N];
-    for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
-#else
-    int64_t *stat = nullptr;
-#endif
 
-    while (true) {
-        // ---- wave 0 decides what happens next and publishes it --------------------------------------------
-        bool first_after_emit = false;
-        int64_t ev_before = 0;
-        if (wave == 0) {
-            int64_t pos = L.p + 1;
-            if (pos < seg_start) pos = seg_start;
-            int mode = 1;
-            if (!ok || pos > lim)
-                mode = 0;
-            else {
-                first_after_emit = after_emit;
-                ev_before = L.n_events;
-                long_seen = 0;
-                const bool go_seq = first_after_emit && pred_long[emit_cls] >= 2;
-                if (seq_credit > 0) {
-                    seq_credit--;  // a stretch where every candidate has long matches: one at a time is cheaper
-                    mode = 2;
-                } else if (go_seq)
-                    mode = 2;
+    while (ok) {
+        int64_t pos = L.p + 1;
+        if (pos < seg_start) pos = seg_start;
+        if (pos > lim) break;
+        const bool first_after_emit = after_emit;
+        const int64_t ev_before = L.n_events;
+        long_seen = 0;
+        int mode = 1;
+        if (seq_credit > 0) {
+            seq_credit--;  // a stretch where every candidate has long matches: one at a time is cheaper
+            mode = 2;
+        } else if (first_after_emit && pred_long[emit_cls] >= 2)
+            mode = 2;
 #ifdef MRZ_NO_BATCH
-                mode = 2;
+        mode = 2;
 #endif
-            }
-            if (lane == 0) {
-                S->Lp = L;
-                S->ctl[MRZ_CTL_MODE] = mode;
-                S->ctl[MRZ_CTL_WIDTH] = width;
-            }
-        }
-        __syncthreads();
-        int mode = mrz_uni(S->ctl[MRZ_CTL_MODE]);
-        if (mode == 0) break;
         int used = 0;
         if (mode == 1) {
-            mrz_lead Lw = S->Lp;
-            const int wd = mrz_uni(S->ctl[MRZ_CTL_WIDTH]);
-            mrz_wide_ret r;
-            mrz_wide_step(C, Lw, S, a.tags, a.bitmap, seg_start, lim, nwords, wd, tid, lane, wave, stat, &r);
-            used = r.used;
-            if (wave == 0) {
-                L = Lw;
-                ok = r.ok;
-                if (r.long_seen) long_seen = 1;
-                // a match that swallowed the rest of the batch: the next batch starts small and regrows
-                if (r.skipped_out)
-                    width = 64;
-                else if (width < MRZ_W)
-                    width = width * 4 > MRZ_W ? MRZ_W : width * 4;
-                if (used <= 2 && r.coop_next) {
-                    if (++low_yield >= MRZ_LOW_YIELD_RUNS) {
-                        seq_credit = MRZ_SEQ_CREDIT;
-                        low_yield = 0;
-                    }
-                } else
-                    low_yield = 0;
+            if (width <= 64) {
+                // a narrow batch (right after a match that swallowed the rest of the previous one): this wave alone,
+                // no workgroup barrier -- repetitive streams run on these
+                mrz_wide_prep<1>(C, L, S, a.tags, a.bitmap, seg_start, lim, nwords, width, lane, lane, 0, stat);
+            } else {
+                if (lane == 0) {
+                    S->Lp = L;
+                    S->ctl[MRZ_CTL_MODE] = 1;
+                    S->ctl[MRZ_CTL_WIDTH] = width;
+                }
+                cmd_seq++;
+                if (lane == 0) mrz_mb_store(&S->cmd, cmd_seq);
+                mrz_wide_prep<MRZ_SEQ_WAVES>(C, L, S, a.tags, a.bitmap, seg_start, lim, nwords, width, tid, lane, wave, stat);
             }
-            if (r.coop_next && r.ok) mode = 2;
+            mrz_wide_ret r;
+            mrz_wide_commit(C, L, S, lane, stat, &r);
+            used = r.used;
+            ok = r.ok;
+            if (r.long_seen) long_seen = 1;
+            // a match that swallowed the rest of the batch: the next batch starts small and regrows
+            if (r.skipped_out)
+                width = 64;
+            else if (width < MRZ_W)
+                width = width * 4 > MRZ_W ? MRZ_W : width * 4;
+            if (used <= 2 && r.coop_next) {
+                if (++low_yield >= MRZ_LOW_YIELD_RUNS) {
+                    seq_credit = MRZ_SEQ_CREDIT;
+                    low_yield = 0;
+                }
+            } else
+                low_yield = 0;
+            if (r.coop_next && ok) mode = 2;
         }
-        if (mode == 2 && wave == 0 && ok) {
+        if (mode == 2 && ok) {
             // ---- cooperative path: the first candidate after L.p (4096-position bitmap window) ---------------
             PROF_T0();
-            int64_t pos = L.p + 1;
+            pos = L.p + 1;
             if (pos < seg_start) pos = seg_start;
             if (pos <= lim) {
                 const int64_t wb = seg_start + ((pos - seg_start) >> 12 << 12);
@@ -206,30 +216,30 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             }
             PROF_ADD(MRZ_ST_T_SEQ);
         }
-        if (wave == 0) {
-            if (first_after_emit) {
-                const bool first_was_long = long_seen && used <= 1;
-                int &c = pred_long[emit_cls];
-                c = first_was_long ? (c < 3 ? c + 1 : 3) : (c > 0 ? c - 1 : 0);
-            }
-            if (L.p == stall_p && L.n_events == stall_ev) {
-                if (++stall > 64) {
-                    if (lane == 0) st->error = 4;
-                    ok = false;
-                }
-            } else {
-                stall = 0;
-                stall_p = L.p;
-                stall_ev = L.n_events;
-            }
-            after_emit = L.n_events != ev_before;
-            if (after_emit) emit_cls = ((emit_cls << 1) & 2) | (L.last_len >= MRZ_GREAT_MATCH ? 1 : 0);
+        if (first_after_emit) {
+            const bool first_was_long = long_seen && used <= 1;
+            int &c = pred_long[emit_cls];
+            c = first_was_long ? (c < 3 ? c + 1 : 3) : (c > 0 ? c - 1 : 0);
         }
-        __syncthreads();
+        if (L.p == stall_p && L.n_events == stall_ev) {
+            if (++stall > 64) {
+                if (lane == 0) st->error = 4;
+                ok = false;
+            }
+        } else {
+            stall = 0;
+            stall_p = L.p;
+            stall_ev = L.n_events;
+        }
+        after_emit = L.n_events != ev_before;
+        if (after_emit) emit_cls = ((emit_cls << 1) & 2) | (L.last_len >= MRZ_GREAT_MATCH ? 1 : 0);
     }
+    // send the other waves home
+    if (lane == 0) S->ctl[MRZ_CTL_MODE] = 0;
+    cmd_seq++;
+    if (lane == 0) mrz_mb_store(&S->cmd, cmd_seq);
 
     // release the helpers, then publish the state for the next segment's launch
-    if (wave != 0) return;
 #if MRZ_HELPER_WGS > 0
     if (lane == 0 && C.gmb) mrz_g_storeu(&C.gmb->quit, 1ull);
 #endif
