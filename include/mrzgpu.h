@@ -78,8 +78,8 @@ typedef struct {
     float encode_ms;
     float crc_ms;
     float total_ms;     /* first launch -> last kernel done */
-    int32_t n_segments;
-    int32_t reserved;
+    int32_t n_segments; /* sequencer launches (segments an emitted match has covered are not launched) */
+    int32_t n_narrow;   /* ... of which ran on the narrow engine (mrz_seq_narrow.hip) */
 } mrz_timings;
 
 /* ---- context ----------------------------------------------------------- */

@@ -169,9 +169,11 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     }
     if (!rc && hipMemcpy(ctx->d_index, ctx->h_index, sizeof(ctx->h_index), hipMemcpyHostToDevice) != hipSuccess)
         rc = MRZ_E_HIP;
-    if (!rc && mrz_sequencer_mailbox_size() && !getenv("MRZ_NO_HELPER_WGS")) {
+    const size_t mbox = mrz_sequencer_mailbox_size() > mrz_seq_narrow_mailbox_size() ? mrz_sequencer_mailbox_size()
+                                                                                     : mrz_seq_narrow_mailbox_size();
+    if (!rc && mbox && !getenv("MRZ_NO_HELPER_WGS")) {
         void *p = nullptr;
-        if (hipMalloc(&p, mrz_sequencer_mailbox_size()) != hipSuccess)
+        if (hipMalloc(&p, mbox) != hipSuccess)
             rc = MRZ_E_NOMEM;
         else
             ctx->d_gmailbox = p;
@@ -348,8 +350,14 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     // The host stays MRZ_SEG_AHEAD segments ahead of the device and looks at the matcher's position of the
     // segment that has just finished: a segment that an emitted match has already covered completely (a stream
     // that repeats itself: one match of gigabytes) needs no tag scan and no sequencer launch at all.
-    int64_t *h_pos = ctx->h_pos;  // pinned; written by the copies below
-    *h_pos = 0;
+    int64_t *h_pos = ctx->h_pos;  // pinned; written by the copies below: p, hint_positions, hint_events, hint_matched
+    h_pos[0] = h_pos[1] = h_pos[2] = h_pos[3] = 0;
+    int engine_pin = 0, n_narrow = 0;
+    {
+        const char *e = getenv("MRZ_SEQ_ENGINE");
+        if (e && !strcmp(e, "wide")) engine_pin = 1;
+        if (e && !strcmp(e, "narrow")) engine_pin = 2;
+    }
     hipEvent_t seg_ev[MRZ_SEG_AHEAD];
     int n_seg_ev = 0;
     for (int k = 0; k < MRZ_SEG_AHEAD && herr == hipSuccess; k++) {
@@ -370,13 +378,29 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         STEP(mrz_launch_tagscan(s, d_buf, n, seg_start, seg_len, ctx->d_index, ctx->d_state, ctx->d_tags,
                                 ctx->d_bitmap));
         PROF_END();
+        // Which engine: the wide one (512 candidates per batch) unless the segments before were one long match after
+        // another (>= 80 % of the positions a launch advanced over lay inside the matches it emitted): then the
+        // narrow engine's shorter chain per match wins.  The hint lags behind like h_pos; the first two launches are
+        // waited for so that it arrives early.  MRZ_SEQ_ENGINE=wide|narrow pins the choice (tests, measurements).
+        bool narrow = false;
+        {
+            const int64_t hp = *(volatile int64_t *)(h_pos + 1), hm = *(volatile int64_t *)(h_pos + 3);
+            narrow = hp > 0 && hm * 10 >= hp * 8;
+            if (engine_pin) narrow = engine_pin == 2;
+        }
+        const int helpers = ctx->farm_helpers >= 0 && ctx->farm_helpers < ctx->farm_default ? ctx->farm_helpers : ctx->farm_default;
         PROF_BEGIN(1);
-        STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                  ctx->d_state, seg_start, seg_len, ctx->d_gmailbox,
-                                  ctx->farm_helpers >= 0 && ctx->farm_helpers < ctx->farm_default ? ctx->farm_helpers
-                                                                                                   : ctx->farm_default));
+        if (narrow)
+            STEP(mrz_launch_sequencer_narrow(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
+                                             ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers));
+        else
+            STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
+                                      ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers));
         PROF_END();
+        if (narrow) n_narrow++;
         STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        STEP(hipMemcpyAsync(h_pos + 1, &ctx->d_state->hint_positions, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (launched < 2 && !engine_pin) STEP(hipStreamSynchronize(s));
         STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));
         launched++;
     }
@@ -391,9 +415,6 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                     "count=%lld min_mask=%lld\n",
                     hs.error, hs.finished, (long long)hs.p, (long long)hs.end, (long long)hs.n_events,
                     (long long)hs.event_cap, (long long)hs.count, (long long)hs.min_mask);
-            fprintf(stderr, "  dbg: n_events=%lld cap=%lld cur_len=%lld cur_p=%lld p=%lld mlen=%lld\n", (long long)hs.pad[0],
-                    (long long)hs.pad[1], (long long)hs.pad[2], (long long)hs.pad[3], (long long)hs.pad[4],
-                    (long long)hs.pad[5]);
             rc = MRZ_E_OVERFLOW;
         }
         E = hs.n_events;
@@ -441,6 +462,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) ctx->timings.total_ms = ms;
         ctx->timings.n_segments = (int32_t)launched;  // segments covered by an emitted match are not launched
+        ctx->timings.n_narrow = (int32_t)n_narrow;
         hipEventDestroy(ev_begin);
         hipEventDestroy(ev_end);
         free(evs);

@@ -44,7 +44,10 @@ struct mrz_seq_state {
     int64_t inserts, tag_hits, tag_misses;  // stats
     int32_t finished;     // main loop has reached `end`
     int32_t error;        // nonzero: event list overflow etc.
-    int64_t pad[8];
+    int64_t hint_positions;  // regime hint of the latest launch: positions it advanced over ...
+    int64_t hint_events;     // ... matches it emitted ...
+    int64_t hint_matched;    // ... and the bytes those matches cover (most positions matched = one long match after another)
+    int64_t pad[5];
     int64_t prof[64];     // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
 };
 

@@ -15,7 +15,11 @@ hipError_t mrz_launch_tagscan(hipStream_t stream, const uint8_t *buf, int64_t n,
 hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
                                 const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st, int64_t seg_start,
                                 int64_t seg_len, void *gmailbox, int n_helpers);
+hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
+                                       const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st, int64_t seg_start,
+                                       int64_t seg_len, void *gmailbox, int n_helpers);
 size_t mrz_sequencer_mailbox_size(void);
+size_t mrz_seq_narrow_mailbox_size(void);
 int mrz_sequencer_default_helpers(int device);
 hipError_t mrz_launch_enc_size(hipStream_t stream, const mrz_event *ev, int64_t E, int64_t n, int cb, int64_t *block_s0,
                                int64_t *block_s1, mrz_enc_totals *totals);

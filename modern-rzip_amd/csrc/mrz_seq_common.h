@@ -553,6 +553,7 @@ struct mrz_lead {  // wave-uniform; what hash_search keeps in locals / rzip_stat
     int64_t min_mask, tag_mask, count, clean_ptr, victim_round;
     int64_t n_events, inserts, tag_hits, tag_misses;
     int64_t last_len;  // length of the last emitted match (scheduling hint only)
+    int64_t mbytes;    // bytes of the matches emitted in this launch (regime hint only)
 };
 
 struct mrz_cfg {
@@ -592,6 +593,7 @@ __device__ __forceinline__ bool mrz_select_emit(const mrz_cfg &C, mrz_lead &L, i
         }
         L.n_events++;
         L.last_len = L.cur_len;
+        L.mbytes += L.cur_len;
         L.last_match = L.cur_p + L.cur_len;
         L.cur_p = L.p = L.last_match;
         L.cur_len = 0;

@@ -38,13 +38,15 @@
 #define MRZ_POOL 1024                 // chunks of 4 tag-equal entries
 #define MRZ_PAIR_MAX (MRZ_POOL * 4)
 #define MRZ_BH_SIZE 2048              // block-hash entries (64-slot blocks written by this batch)
-#define MRZ_BH_WRITERS 3
+#define MRZ_BH_WRITERS 5
 #define MRZ_CW_WORDS 32               // cull window: 32 x 64 slots ahead of tag_clean_ptr
 #define MRZ_NW_MAX 192
 #define MRZ_XW_MAX 48
 #ifndef MRZ_BULK_MIN
 #define MRZ_BULK_MIN 96              // leading lanes worth a workgroup-wide bulk commit
 #endif
+#define MRZ_OV_MAX 6   // overlay entries of one lane: up to 3 earlier writers, insert + occupant slot each
+#define MRZ_WR_MAX 3
 #define MRZ_OFF_BITS 40
 #define MRZ_OFF_MASK ((1ull << MRZ_OFF_BITS) - 1)
 
@@ -77,7 +79,7 @@ struct mrz_wide_lds {
     int64_t blen[MRZ_W], boff[MRZ_W];  // best match of the lane's entries under the last_match of the preparation
     int brev[MRZ_W];
     unsigned short bhm[MRZ_W];         // tag_hits << 8 | tag_misses of that look-up
-    unsigned short dep0[MRZ_W], dep1[MRZ_W];  // lanes whose speculated writes an overlay walk has assumed (MRZ_W: none)
+    unsigned short dep0[MRZ_W], dep1[MRZ_W], dep2[MRZ_W];  // lanes whose speculated writes an overlay walk has assumed
     unsigned char exec[MRZ_W];         // 0 not yet, 1 committed as prepared, 2 dropped / went through the cooperative path
     int xw_n;                          // slots written by cooperative hand-overs inside this batch
     int xw_slot[MRZ_XW_MAX];
@@ -268,8 +270,8 @@ __device__ __forceinline__ void mrz_pair_eval(unsigned raw, int64_t q, int64_t o
 // ---- phase B: the probe walk of one lane (and of the occupant it displaces) -----------------------------
 struct mrz_ov {  // writes of earlier lanes laid over the table for an overlay walk
     int n;
-    int slot[4];
-    int64_t off[4], t[4];
+    int slot[MRZ_OV_MAX];
+    int64_t off[MRZ_OV_MAX], t[MRZ_OV_MAX];
 };
 
 struct mrz_wl {
@@ -283,7 +285,7 @@ __device__ __forceinline__ mrz_slot mrz_tab_load(const mrz_slot *tab, int slot, 
     mrz_slot e = tab[slot];
     if (ov) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < MRZ_OV_MAX; k++)
             if (k < ov->n && ov->slot[k] == slot) {  // a later overlay entry wins (written later)
                 e.off = ov->off[k];
                 e.t = ov->t[k];
@@ -388,7 +390,7 @@ __device__ static void mrz_wide_walk(const mrz_cfg &C, mrz_wide_lds *S, bool go,
             if (USE_OV) {  // the straggler's overlay, broadcast to its wave
                 ov_o.n = mrz_lane_read(ovl.n, ol);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < MRZ_OV_MAX; k++) {
                     ov_o.slot[k] = mrz_lane_read(ovl.slot[k], ol);
                     ov_o.off[k] = mrz_bcast64(ovl.off[k], ol);
                     ov_o.t[k] = mrz_bcast64(ovl.t[k], ol);
@@ -544,7 +546,7 @@ __device__ static void mrz_wide_walk(const mrz_cfg &C, mrz_wide_lds *S, bool go,
             if (USE_OV) {
                 ov_o.n = mrz_lane_read(ovl.n, ol);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < MRZ_OV_MAX; k++) {
                     ov_o.slot[k] = mrz_lane_read(ovl.slot[k], ol);
                     ov_o.off[k] = mrz_bcast64(ovl.off[k], ol);
                     ov_o.t[k] = mrz_bcast64(ovl.t[k], ol);
@@ -672,9 +674,9 @@ __device__ static int mrz_bh_readers(const mrz_wide_lds *S, int gl, int a, int l
                         if (wl >= gl) continue;
                         if (!mrz_writes_hit(S, wl, a, la, b, lb, smask)) continue;
                         bool dup = false;
-                        for (int z = 0; z < found && z < 2; z++) dup = dup || wr[z] == wl;
+                        for (int z = 0; z < found && z < MRZ_WR_MAX; z++) dup = dup || wr[z] == wl;
                         if (!dup) {
-                            if (found < 2) wr[found] = wl;
+                            if (found < MRZ_WR_MAX) wr[found] = wl;
                             found++;
                         }
                     }
@@ -883,7 +885,7 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
     ST_COUNT(MRZ_ST_X_SAME, cplx && wl.why == 4);
     int h = (int)(t & C.slot_mask);
     int len1 = (act && !cplx) ? ((wl.fe - h) & smask) + 1 : 0;
-    int dep0 = -1, dep1 = -1;  // lanes whose writes this lane's (overlay) walk has assumed
+    int dep0 = -1, dep1 = -1, dep2 = -1;  // lanes whose writes this lane's (overlay) walk has assumed
 
     // post-walk rules that involve the cull window; publishes the lane's facts
     auto post_walk = [&]() {
@@ -932,7 +934,7 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
     }
     PROF_ADD(MRZ_ST_T_WALK);
     mrz_prep_sync<NW>();
-    int wr[2] = { -1, -1 };
+    int wr[MRZ_WR_MAX] = { -1, -1, -1 };
     int nwr = 0;
     if (act && !cplx) {
         nwr = mrz_bh_readers(S, tid, h, len1, wl.h2, wl.len2, smask, wr);
@@ -947,25 +949,36 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
         const bool win_stale = act && !cplx && conf && nwr == 0;  // stale only because of the cull window
         S->lf[tid] = (unsigned char)((conf ? 1 : 0) | (cplx ? 2 : 0) | (act ? 4 : 0));
         mrz_prep_sync<NW>();
-        bool elig = act && !cplx && conf && !win_stale && nwr >= 1 && nwr <= 2;
+        bool elig = act && !cplx && conf && !win_stale && nwr >= 1 && nwr <= MRZ_WR_MAX;
         int cwhy = 0;  // why a stale lane could not be repaired here (diagnostics)
         if (act && !cplx && conf && !elig) cwhy = win_stale ? 1 : 4;
         mrz_ov ov;
         ov.n = 0;
-        int ov_src[4] = { -1, -1, -1, -1 };  // writer lane * 2 + (0: its insert slot, 1: its occupant's new slot)
+        int ov_src[MRZ_OV_MAX];  // writer lane * 2 + (0: its insert slot, 1: its occupant's new slot)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < MRZ_OV_MAX; k++) {
+            ov_src[k] = -1;
             ov.slot[k] = -1;
             ov.off[k] = 0;
             ov.t[k] = 0;
         }
         if (elig) {
-            if (nwr == 2 && wr[0] > wr[1]) {
-                const int z = wr[0];
-                wr[0] = wr[1];
-                wr[1] = z;
+            // in lane order: a later writer's store is the one that stays
+#define MRZ_CSWAP(a, b)            \
+    if (wr[a] > wr[b]) {           \
+        const int z__ = wr[a];     \
+        wr[a] = wr[b];             \
+        wr[b] = z__;               \
+    }
+            if (nwr >= 2) MRZ_CSWAP(0, 1)
+            if (nwr >= 3) {
+                MRZ_CSWAP(1, 2)
+                MRZ_CSWAP(0, 1)
             }
-            for (int k = 0; k < nwr; k++) {
+#undef MRZ_CSWAP
+#pragma unroll
+            for (int k = 0; k < MRZ_WR_MAX; k++) {
+                if (k >= nwr) continue;
                 const int i = wr[k];
                 const int ki = S->kind[i];
                 if ((S->lf[i] & 3) != 0 || ki == 3 || ki == 255) {
@@ -980,23 +993,24 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
                 if (!cwhy) cwhy = 1;
             }
         }
-        if (elig) {
-            for (int k = 0; k < nwr; k++) {
+        // entries 2k (the occupant writer k displaces) and 2k + 1 (its insert), statically indexed so that the
+        // overlay stays in registers; unused entries keep slot -1 and never match
+#pragma unroll
+        for (int k = 0; k < MRZ_WR_MAX; k++)
+            if (elig && k < nwr) {
                 const int i = wr[k];
                 if (S->kind[i] == 2) {
-                    ov.slot[ov.n] = S->w2[i];
-                    ov.off[ov.n] = S->occ_off[i];
-                    ov.t[ov.n] = S->occ_t[i];
-                    ov_src[ov.n] = i * 2 + 1;
-                    ov.n++;
+                    ov.slot[2 * k] = S->w2[i];
+                    ov.off[2 * k] = S->occ_off[i];
+                    ov.t[2 * k] = S->occ_t[i];
+                    ov_src[2 * k] = i * 2 + 1;
                 }
-                ov.slot[ov.n] = S->wslot[i];
-                ov.off[ov.n] = S->q[i];
-                ov.t[ov.n] = S->t[i];
-                ov_src[ov.n] = i * 2;
-                ov.n++;
+                ov.slot[2 * k + 1] = S->wslot[i];
+                ov.off[2 * k + 1] = S->q[i];
+                ov.t[2 * k + 1] = S->t[i];
+                ov_src[2 * k + 1] = i * 2;
             }
-        }
+        ov.n = MRZ_OV_MAX;
         const mrz_u64 m_el = __ballot(elig);
         int n_el;
         (void)mrz_wide_incl<NW>(lane == 0 ? __popcll(m_el) : 0, S->wt5, lane, wave, &n_el);
@@ -1013,7 +1027,7 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
                 // Only the insert slot may tie; an occupant moving onto a writer's slot waits for its turn.
                 int tie_src = -1;
                 if (good && ins)
-                    for (int k = 0; k < 4; k++)
+                    for (int k = 0; k < MRZ_OV_MAX; k++)
                         if (k < ov.n) {
                             if (wn.kind == 2 && ov.slot[k] == wn.w2) {
                                 good = false;
@@ -1024,11 +1038,14 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
                 const int nlen1 = good ? ((wn.fe - h) & smask) + 1 : 0;
                 if (good) {
                     // no other earlier writer may reach into what it has read now
-                    int wr2[2] = { -1, -1 };
+                    int wr2[MRZ_WR_MAX] = { -1, -1, -1 };
                     const int n2 = mrz_bh_readers(S, tid, h, nlen1, wn.h2, wn.len2, smask, wr2);
                     if (n2 < 0 || n2 > nwr) good = false;
-                    for (int k = 0; k < n2 && k < 2 && good; k++)
-                        if (wr2[k] != wr[0] && (nwr < 2 || wr2[k] != wr[1])) good = false;
+                    for (int k = 0; k < n2 && k < MRZ_WR_MAX && good; k++) {
+                        bool known = false;
+                        for (int z = 0; z < nwr; z++) known = known || wr2[k] == wr[z];
+                        if (!known) good = false;
+                    }
                     if (cw_len > 0 && (mrz_ranges_meet(h, nlen1, (int)cw_base, cw_len, smask) ||
                                        mrz_ranges_meet(wn.h2, wn.len2, (int)cw_base, cw_len, smask)))
                         good = false;
@@ -1064,7 +1081,8 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
                     len1 = nlen1;
                     conf = false;
                     dep0 = wr[0];
-                    dep1 = nwr == 2 ? wr[1] : -1;
+                    dep1 = nwr >= 2 ? wr[1] : -1;
+                    dep2 = nwr >= 3 ? wr[2] : -1;
                     S->len1[tid] = len1;
                     S->h2[tid] = wl.h2;
                     S->len2[tid] = wl.len2;
@@ -1160,6 +1178,7 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
         S->bhm[tid] = (unsigned short)((bh << 8) | bm);
         S->dep0[tid] = (unsigned short)(dep0 >= 0 ? dep0 : MRZ_W);
         S->dep1[tid] = (unsigned short)(dep1 >= 0 ? dep1 : MRZ_W);
+        S->dep2[tid] = (unsigned short)(dep2 >= 0 ? dep2 : MRZ_W);
         S->len1[tid] = (act && !cplx) ? len1 : 0;
         S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
         bool revs = false;
@@ -1334,8 +1353,10 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             break;
         }
         const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
+        const int f_s = mrz_uni(S->lf[s]);
+        const bool s_quick = (f_s & MRZ_LF_ACT) && (f_s & (MRZ_LF_CONF | MRZ_LF_CPLX));  // no need to look at the window
         const int i = s + lane;
-        const bool have = i < nb;
+        const bool have = !s_quick && i < nb;
         const int ii = have ? i : nb - 1;
         const int f = have ? S->lf[ii] : 0;
         const bool act = (f & MRZ_LF_ACT) != 0, ins = (f & MRZ_LF_INS) != 0, cplx = (f & MRZ_LF_CPLX) != 0;
@@ -1345,8 +1366,8 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
         // cooperative hand-over inside this batch wrote into what it has read
         if (have && act && !cplx && !conf) {
             // (a lane of this very window either commits together with this one or cuts the segment before it)
-            const int d0 = S->dep0[ii], d1 = S->dep1[ii];
-            if ((d0 < s && S->exec[d0] != 1) || (d1 < s && S->exec[d1] != 1)) conf = true;
+            const int d0 = S->dep0[ii], d1 = S->dep1[ii], d2 = S->dep2[ii];
+            if ((d0 < s && S->exec[d0] != 1) || (d1 < s && S->exec[d1] != 1) || (d2 < s && S->exec[d2] != 1)) conf = true;
             const int nx = S->xw_n;
             if (nx > 0) {
                 const int h = S->h[ii], len1 = S->len1[ii], h2 = S->h2[ii], len2 = S->len2[ii];
@@ -1384,9 +1405,11 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
         const mrz_u64 m_stop = __ballot(stop);
         int nseg = nb - s < 64 ? nb - s : 64;
         if (m_stop) nseg = __ffsll((long long)m_stop) - 1;
+        if (s_quick) nseg = 0;
         if (nseg == 0) {
             // ---- lane s cannot be committed as prepared ---------------------------------------------------------
-            const bool s_cplx = mrz_lane_read((int)cplx, 0) != 0, s_conf = mrz_lane_read((int)conf, 0) != 0;
+            const bool s_cplx = s_quick ? (f_s & MRZ_LF_CPLX) != 0 : mrz_lane_read((int)cplx, 0) != 0;
+            const bool s_conf = s_quick ? (f_s & MRZ_LF_CONF) != 0 : mrz_lane_read((int)conf, 0) != 0;
             if (s_cplx || s_conf) {
                 // stale (an earlier lane wrote into what it read) or beyond the per-lane walk (long chain, deep
                 // cascade): the cooperative path replays this one candidate in full against the table as committed
@@ -1628,12 +1651,22 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             }
             L.n_events++;
             L.last_len = L.cur_len;
+            L.mbytes += L.cur_len;
             L.last_match = L.cur_p + L.cur_len;
             L.cur_p = L.p = L.last_match;
             L.cur_len = 0;
             if (L.last_match >= q_e) {
-                // the lanes inside the match are dropped: first lane behind it
+                // the lanes inside the match are dropped: first lane behind it (mostly still in this window)
                 int lo = s + y, hi = nb;
+                {
+                    const mrz_u64 m_beh = __ballot(have && lane >= y && q > L.last_match);
+                    if (m_beh)
+                        lo = hi = s + (__ffsll((long long)m_beh) - 1);
+                    else if (s + 64 < nb)
+                        lo = s + 64;
+                    else
+                        lo = hi = nb;
+                }
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (mrz_uni64(S->q[mid]) > L.last_match)

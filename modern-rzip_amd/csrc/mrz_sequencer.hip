@@ -79,7 +79,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     L.tag_hits = st->tag_hits;
     L.tag_misses = st->tag_misses;
     L.last_len = 0;
+    L.mbytes = 0;
 
+    const int64_t hint_p0 = L.p, hint_ev0 = L.n_events;
     const int64_t seg_start = a.seg_start;
     const int64_t seg_end = a.seg_start + a.seg_len;
     const int64_t lim = (C.end < seg_end - 1) ? C.end : seg_end - 1;  // last candidate position of this launch
@@ -259,6 +261,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         st->tag_hits = L.tag_hits;
         st->tag_misses = L.tag_misses;
         st->finished = L.p >= C.end ? 1 : 0;
+        st->hint_positions = L.p - hint_p0;
+        st->hint_events = L.n_events - hint_ev0;
+        st->hint_matched = L.mbytes;
 #ifdef MRZ_SEQ_STATS
         for (int k = 0; k < MRZ_ST_N; k++) st->prof[k] += stat[k];
 #endif

@@ -5,10 +5,14 @@ import torch
 import modern_rzip_amd as m
 from modern_rzip_amd import workloads as w
 from tests import _util
+LIB = None
+if "--prof" in sys.argv:
+    sys.argv.remove("--prof")
+    LIB = m.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_prof", "libmrzgpu_prof.so"))
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 nper = int(gib * (1 << 30)) // 65536
 t = w.rep64k_device(nper, "cuda")
-with m.RzipContext(max_chunk=t.numel()) as ctx:
+with m.RzipContext(max_chunk=t.numel(), lib=LIB) as ctx:
     for i in range(2):
         ctx.victim_round = 0
         t0 = time.time(); res, s0, s1 = ctx.rzip_chunk(t); dt = time.time() - t0
