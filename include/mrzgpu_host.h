@@ -31,9 +31,25 @@ typedef struct {
     int device;                 /* HIP device ordinal */
 } mrz_control;
 
-/* file -> file, as `mrzip -n -L<level> [-w|-U] -m<ramsize>` would write it.
- * stats (may be NULL) receives the per-file totals printed at -vv. */
+/* As `mrzip -n -L<level> [-w|-U] -m<ramsize>` would write it.  fd_in a regular file: the FILE form of the chunk loop
+ * (size from fstat, chunks of max_chunk bytes read one at a time, src/rzip.c:864-866,915-1061), fd_out must seek.
+ * fd_in anything else (a pipe): the STDIN form, see mrz_rzip_stream; the output counts as STDOUT if it cannot seek.
+ * The archive is written chunk by chunk.  stats (may be NULL) receives the totals printed at -vv. */
 int mrz_rzip_fd(const mrz_control *control, int fd_in, int fd_out, mrz_stats *stats);
+
+/* The STDIN form of rzip_fd's chunk loop (mmap_stdin, src/rzip.c:700-732; the loop :915-1061 with STDIN set;
+ * setup_ram, src/util.c:156-164): the size is unknown, so every chunk is max_mmap = min(page-rounded maxram,
+ * max_chunk) bytes, maxram = ramsize / 3 (ramsize / 6 with to_stdout), until read() returns 0; the chunk in which
+ * that happens is shrunk and carries the eof flag -- one more, EMPTY chunk when the input length is a multiple of
+ * the chunk size; the stream block size is fixed at the first chunk from the bytes read so far (src/stream.c:803-914).
+ * to_stdout = 0: the header is written last, with the total size (src/mrzip.c:1132).  to_stdout = 1: the header goes
+ * out first (src/stream.c:1202-1205) and holds the size only if the input ended within the first chunk
+ * (src/mrzip.c:137-140); nothing is ever sought, so fd_out may be a pipe.  -U (unlimited) is refused: it takes the
+ * window from the file size. */
+int mrz_rzip_stream(const mrz_control *control, int fd_in, int fd_out, int to_stdout, mrz_stats *stats);
+/* the same with `in` standing for what read() would deliver (tests) */
+int mrz_rzip_stream_buffer(const mrz_control *control, const void *in, int64_t n, int to_stdout, void **out,
+                           int64_t *out_len, mrz_stats *stats, uint8_t *md5_out);
 
 /* memory -> memory variant of the same path.  *out is malloc'd by the library
  * (release with mrz_free); md5_out (may be NULL) gets the 16 trailing bytes. */

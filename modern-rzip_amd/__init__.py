@@ -24,6 +24,8 @@ from .binding import (  # noqa: E402,F401
     load_library,
     chunk_bytes,
     rzip_buffer,
+    rzip_stream_buffer,
+    rzip_fd,
     runzip_buffer,
     rzip_pipeline,
     MEM_HOST,
@@ -32,5 +34,5 @@ from .binding import (  # noqa: E402,F401
 
 __all__ = [
     "MrzError", "RzipContext", "ChunkResult", "Stats", "Timings", "Control", "lib_path", "load_library",
-    "chunk_bytes", "rzip_buffer", "runzip_buffer", "rzip_pipeline", "MEM_HOST", "MEM_DEVICE",
+    "chunk_bytes", "rzip_buffer", "rzip_stream_buffer", "rzip_fd", "runzip_buffer", "rzip_pipeline", "MEM_HOST", "MEM_DEVICE",
 ]

@@ -121,6 +121,9 @@ def load_library(path=None):
         lib.mrz_rzip_buffer.argtypes = [ctypes.POINTER(Control), vp, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                         ctypes.POINTER(Stats), vp]
         lib.mrz_rzip_fd.argtypes = [ctypes.POINTER(Control), ci, ci, ctypes.POINTER(Stats)]
+        lib.mrz_rzip_stream.argtypes = [ctypes.POINTER(Control), ci, ci, ci, ctypes.POINTER(Stats)]
+        lib.mrz_rzip_stream_buffer.argtypes = [ctypes.POINTER(Control), vp, i64, ci, ctypes.POINTER(vp),
+                                               ctypes.POINTER(i64), ctypes.POINTER(Stats), ctypes.c_char_p]
         lib.mrz_free.argtypes = [vp]
         lib.mrz_free.restype = None
     if path is None:
@@ -327,6 +330,35 @@ def rzip_buffer(data, level=7, window=0, unlimited=False, ramsize=60 << 30, devi
         return ctypes.string_at(out, out_len.value), st, md5.raw
     finally:
         lib.mrz_free(out)
+
+
+def rzip_stream_buffer(data, to_stdout=False, level=7, window=0, ramsize=60 << 30, device=0, lib=None):
+    """`mrzip -n` reading STDIN (mrz_rzip_stream_buffer: the STDIN form of rzip_fd's chunk loop, `data` standing
+    for what read() delivers).  Returns (archive bytes, Stats, md5 bytes)."""
+    lib = lib or load_library()
+    ctl = Control(level, level, window, 0, ramsize, 4096, 1, device)
+    ptr, n, where, keep = _as_ptr(data)
+    if where != MEM_HOST:
+        raise MrzError("rzip_stream_buffer takes host memory")
+    out = ctypes.c_void_p()
+    out_len = ctypes.c_int64()
+    st = Stats()
+    md5 = ctypes.create_string_buffer(16)
+    _check(lib, lib.mrz_rzip_stream_buffer(ctypes.byref(ctl), ptr, n, 1 if to_stdout else 0, ctypes.byref(out),
+                                           ctypes.byref(out_len), ctypes.byref(st), md5))
+    try:
+        return ctypes.string_at(out, out_len.value), st, md5.raw
+    finally:
+        lib.mrz_free(out)
+
+
+def rzip_fd(fd_in, fd_out, level=7, window=0, unlimited=False, ramsize=60 << 30, device=0, lib=None):
+    """mrz_rzip_fd on two open file descriptors (a regular file, or a pipe = the STDIN form).  Returns Stats."""
+    lib = lib or load_library()
+    ctl = Control(level, level, window, 1 if unlimited else 0, ramsize, 4096, 1, device)
+    st = Stats()
+    _check(lib, lib.mrz_rzip_fd(ctypes.byref(ctl), fd_in, fd_out, ctypes.byref(st)))
+    return st
 
 
 def runzip_buffer(mrz, device=0, lib=None):

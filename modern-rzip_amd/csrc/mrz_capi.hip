@@ -446,6 +446,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         STEP(hipStreamSynchronize(s));
     }
 
+    ctx->timings.n_segments = (int32_t)launched;  // segments covered by an emitted match are not launched
+    ctx->timings.n_narrow = (int32_t)n_narrow;
     if (ctx->profiling) {
         hipStreamSynchronize(s);
         for (int i = 0; i < nev; i++) {
@@ -461,8 +463,6 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         }
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev_begin, ev_end) == hipSuccess) ctx->timings.total_ms = ms;
-        ctx->timings.n_segments = (int32_t)launched;  // segments covered by an emitted match are not launched
-        ctx->timings.n_narrow = (int32_t)n_narrow;
         hipEventDestroy(ev_begin);
         hipEventDestroy(ev_end);
         free(evs);

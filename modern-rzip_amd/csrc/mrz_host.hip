@@ -5,7 +5,11 @@
 // src/rzip.c:488-505).  MD5 is a strictly serial hash; it overlaps the GPU work.
 #include <errno.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <new>
+#include <stdexcept>
 
 #include <condition_variable>
 #include <deque>
@@ -220,43 +224,197 @@ struct Sink {
     }
 };
 
-int run_file(const mrz_control *ctl, const uint8_t *in, int64_t n, std::vector<uint8_t> &out, mrz_stats *stats,
-             uint8_t *md5_out) {
-    if (!ctl || ctl->rzip_compression_level < 1 || ctl->rzip_compression_level > 9 || n < 0) return MRZ_E_ARG;
-    if (ctl->hash_code != 1 && ctl->hash_code != 0) return MRZ_E_ARG;  // MD5 only (reference default)
+// ---- where the chunks come from, where the archive goes ---------------------------------------------------
+// The chunk loop of rzip_fd (src/rzip.c:915-1061) in its two forms: a FILE, whose size is known -- chunks of
+// max_chunk bytes, the last one carries the eof flag (:1049) -- and STDIN (mmap_stdin :700-732) -- chunks of
+// max_mmap bytes until read() returns 0; the chunk in which that happens is shrunk and carries the eof flag,
+// which is one more, empty chunk when the input length is a multiple of the chunk size.
+struct Source {
+    virtual ~Source() {}
+    // next chunk into `buf` (resized); *eof: the reference's control->eof for this chunk; returns an MRZ_ code
+    virtual int next(std::vector<uint8_t> &buf, int *eof) = 0;
+    virtual bool more() const = 0;  // while (!pass || len > 0 || (STDIN && !stdin_eof))
+};
+
+struct Reader {  // bytes from memory or from a file descriptor
+    const uint8_t *mem = nullptr;
+    int64_t mem_n = 0, mem_at = 0;
+    int fd = -1;
+    // read(): up to `want` bytes, 0 at the end of the input, < 0 on error
+    int64_t get(uint8_t *dst, int64_t want) {
+        if (fd < 0) {
+            const int64_t k = mem_n - mem_at < want ? mem_n - mem_at : want;
+            if (k > 0) memcpy(dst, mem + mem_at, (size_t)k);
+            mem_at += k;
+            return k;
+        }
+        for (;;) {
+            const ssize_t r = read(fd, dst, (size_t)(want > (1ll << 30) ? (1ll << 30) : want));
+            if (r < 0 && errno == EINTR) continue;
+            return (int64_t)r;
+        }
+    }
+    // fill dst[0..want) unless the input ends first; returns the bytes got, *hit_end if a read returned 0
+    int64_t fill(uint8_t *dst, int64_t want, bool *hit_end) {
+        int64_t got = 0;
+        *hit_end = false;
+        while (got < want) {
+            const int64_t r = get(dst + got, want - got);
+            if (r < 0) return -1;
+            if (r == 0) {
+                *hit_end = true;
+                break;
+            }
+            got += r;
+        }
+        return got;
+    }
+};
+
+struct FileSource : Source {  // size known up front
+    Reader rd;
+    int64_t left, max_chunk;
+    int pass = 0;
+    FileSource(const Reader &r, int64_t n, int64_t mc) : rd(r), left(n), max_chunk(mc) {}
+    bool more() const override { return !pass || left > 0; }
+    int next(std::vector<uint8_t> &buf, int *eof) override {
+        const int64_t csz = max_chunk < left ? max_chunk : left;
+        buf.resize((size_t)csz);
+        bool hit;
+        if (rd.fill(buf.data(), csz, &hit) != csz) return MRZ_E_ARG;  // the file shrank under us
+        *eof = csz == left;
+        left -= csz;
+        pass++;
+        return MRZ_OK;
+    }
+};
+
+struct StdinSource : Source {  // size unknown: mmap_stdin
+    Reader rd;
+    int64_t max_mmap;
+    bool seen_eof = false;
+    StdinSource(const Reader &r, int64_t mm) : rd(r), max_mmap(mm) {}
+    bool more() const override { return !seen_eof; }
+    int next(std::vector<uint8_t> &buf, int *eof) override {
+        buf.resize((size_t)max_mmap);
+        bool hit;
+        const int64_t got = rd.fill(buf.data(), max_mmap, &hit);
+        if (got < 0) return MRZ_E_ARG;
+        buf.resize((size_t)got);  // "Shrinking chunk"
+        seen_eof = hit;
+        *eof = hit ? 1 : 0;
+        return MRZ_OK;
+    }
+};
+
+struct Out {  // the archive: memory, or a file descriptor written chunk by chunk
+    std::vector<uint8_t> *vec = nullptr;
+    int fd = -1;
+    int put(const uint8_t *p, size_t n) {
+        if (vec) {
+            vec->insert(vec->end(), p, p + n);
+            return MRZ_OK;
+        }
+        size_t off = 0;
+        while (off < n) {
+            const ssize_t w = write(fd, p + off, n - off);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                return MRZ_E_ARG;
+            }
+            off += (size_t)w;
+        }
+        return MRZ_OK;
+    }
+    int put_at0(const uint8_t *p, size_t n) {  // fdout_seekto(0) + put_fdout, src/mrzip.c:176-178
+        if (vec) {
+            memcpy(vec->data(), p, n);
+            return MRZ_OK;
+        }
+        size_t off = 0;
+        while (off < n) {
+            const ssize_t w = pwrite(fd, p + off, n - off, (off_t)off);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                return MRZ_E_ARG;
+            }
+            off += (size_t)w;
+        }
+        return MRZ_OK;
+    }
+};
+
+void fill_magic(uint8_t mg[20], const mrz_control *ctl, int64_t st_size) {  // write_magic, src/mrzip.c:127-188
+    memset(mg, 0, 20);
+    mg[0] = 'M';
+    mg[1] = 'R';
+    mg[2] = 'Z';
+    mg[3] = 'I';
+    mg[4] = 0;  // MRZIP_MAJOR
+    mg[5] = 9;  // MRZIP_MINOR
+    for (int i = 0; i < 8; i++) mg[6 + i] = (uint8_t)((uint64_t)st_size >> (8 * i));
+    mg[14] = 1;  // hash_code: MD5
+    mg[18] = (uint8_t)((ctl->rzip_compression_level << 4) + ctl->compression_level);
+}
+
+// stdin_mode: 0 file (st_size known), 1 STDIN -> file, 2 STDIN -> STDOUT
+int run_chunks(const mrz_control *ctl, Source &src, int stdin_mode, int64_t st_size_known, int64_t open_chunk, Out &out,
+               mrz_stats *stats, uint8_t *md5_out) {
     const int64_t page = ctl->page_size > 0 ? ctl->page_size : 4096;
-    int64_t bufsize = 0;
-    const int64_t max_chunk = mrz_plan(ctl, n, &bufsize);
-
-    // whole-file hash on a helper thread while the GPU works (src/rzip.c:1069-1090)
-    uint8_t md5[16];
-    std::thread hasher([&]() {
-        Md5 h;
-        h.update(in, (size_t)n);
-        h.finish(md5);
-    });
-
     mrz_ctx *ctx = nullptr;
-    int rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, max_chunk < n ? max_chunk : n);
+    int rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, open_chunk);
+    if (rc) return rc;
     mrz_stats total;
     memset(&total, 0, sizeof(total));
-    out.clear();
-    out.resize(20, 0);  // header placeholder (compress_file, src/mrzip.c:1126)
-    if (!rc) {
-        Sink sink(out, bufsize);
-        std::vector<uint8_t> s0, s1;
-        int64_t victim_round = 0;  // first rzip_fd call of the process
-        int64_t left = n, pos = 0;
-        int pass = 0;
-        while (!rc && (!pass || left > 0)) {  // chunk loop, src/rzip.c:915-1061
-            const int64_t csz = max_chunk < left ? max_chunk : left;
+    Md5 md5h;  // whole-input hash (src/rzip.c:1069-1090), fed chunk by chunk on a helper thread beside the GPU
+    uint8_t md5[16], mg[20];
+    std::vector<uint8_t> chunk, piece, s0, s1;
+    int64_t bufsize = 0, st_size = 0, victim_round = 0;  // victim_round: first rzip_fd call of the process
+    int nch = 0;
+    try {
+        if (stdin_mode != 2) {  // header placeholder (compress_file, src/mrzip.c:1126)
+            memset(mg, 0, 20);
+            rc = out.put(mg, 20);
+        }
+        Sink sink(piece, 0);
+        while (!rc && src.more()) {
+            int eof = 0;
+            rc = src.next(chunk, &eof);
+            if (rc) break;
+            const int64_t csz = (int64_t)chunk.size();
+            st_size += csz;
+            if (!nch) {
+                // the block size is fixed at the first open_stream_out (src/stream.c:803-914, NO_COMPRESS, one thread)
+                if (stdin_mode) {
+                    const int64_t usable = ctl->ramsize / (stdin_mode == 2 ? 6 : 3);  // setup_ram, src/util.c:156-164
+                    const int64_t chunk_limit = csz < page ? page : csz;
+                    int64_t limit = usable;
+                    if (st_size > 0 && st_size < limit)
+                        limit = st_size > kStreamMin ? st_size : kStreamMin;
+                    else if (limit > chunk_limit)
+                        limit = chunk_limit;
+                    bufsize = page_ceil(limit, page);
+                } else
+                    mrz_plan(ctl, st_size_known, &bufsize);
+                sink.bufsize = bufsize;
+                if (stdin_mode == 2) {
+                    // STDOUT: the first block writes the magic header (src/stream.c:1202-1205); the size is only in
+                    // it if the input has already ended (write_magic, src/mrzip.c:137-140)
+                    fill_magic(mg, ctl, eof ? st_size : 0);
+                    rc = out.put(mg, 20);
+                    if (rc) break;
+                }
+            }
+            std::thread hasher([&]() { md5h.update(chunk.data(), (size_t)csz); });
             const int cb = mrz_chunk_bytes(csz);
             mrz_chunk_result res;
-            rc = mrz_rzip_chunk(ctx, in + pos, csz, MRZ_MEM_HOST, cb, &victim_round, &res);
-            if (rc) break;
-            s0.resize((size_t)res.s0_len);
-            s1.resize((size_t)res.s1_len);
-            rc = mrz_fetch_streams(ctx, s0.data(), s1.data());
+            rc = mrz_rzip_chunk(ctx, chunk.data(), csz, MRZ_MEM_HOST, cb, &victim_round, &res);
+            if (!rc) {
+                s0.resize((size_t)res.s0_len);
+                s1.resize((size_t)res.s1_len);
+                rc = mrz_fetch_streams(ctx, s0.data(), s1.data());
+            }
+            hasher.join();
             if (rc) break;
             total.inserts += res.stats.inserts;
             total.literals += res.stats.literals;
@@ -265,30 +423,68 @@ int run_file(const mrz_control *ctl, const uint8_t *in, int64_t n, std::vector<u
             total.match_bytes += res.stats.match_bytes;
             total.tag_hits += res.stats.tag_hits;
             total.tag_misses += res.stats.tag_misses;
-            sink.begin_chunk(csz, cb, csz == left, page);
+            piece.clear();
+            sink.begin_chunk(csz, cb, eof, page);
             rc = sink.feed(s0.data(), res.s0_len, s1.data(), res.s1_len);
-            pos += csz;
-            left -= csz;
-            pass++;
+            if (!rc) rc = out.put(piece.data(), piece.size());
+            nch++;
         }
+        if (!rc) {
+            md5h.finish(md5);
+            rc = out.put(md5, 16);
+        }
+        if (!rc && stdin_mode != 2) {  // compress_file writes the header last (src/mrzip.c:1132)
+            fill_magic(mg, ctl, st_size);
+            rc = out.put_at0(mg, 20);
+        }
+    } catch (const std::bad_alloc &) {
+        rc = MRZ_E_NOMEM;
     }
-    hasher.join();
-    if (ctx) mrz_close(ctx);
+    mrz_close(ctx);
     if (rc) return rc;
-    out.insert(out.end(), md5, md5 + 16);
-    // write_magic, src/mrzip.c:127-188
-    uint8_t *mg = out.data();
-    mg[0] = 'M';
-    mg[1] = 'R';
-    mg[2] = 'Z';
-    mg[3] = 'I';
-    mg[4] = 0;  // MRZIP_MAJOR
-    mg[5] = 9;  // MRZIP_MINOR
-    for (int i = 0; i < 8; i++) mg[6 + i] = (uint8_t)((uint64_t)n >> (8 * i));
-    mg[14] = 1;  // hash_code: MD5
-    mg[18] = (uint8_t)((ctl->rzip_compression_level << 4) + ctl->compression_level);
     if (stats) *stats = total;
     if (md5_out) memcpy(md5_out, md5, 16);
+    return MRZ_OK;
+}
+
+int check_control(const mrz_control *ctl) {
+    if (!ctl || ctl->rzip_compression_level < 1 || ctl->rzip_compression_level > 9) return MRZ_E_ARG;
+    if (ctl->hash_code != 1 && ctl->hash_code != 0) return MRZ_E_ARG;  // MD5 only (reference default)
+    return MRZ_OK;
+}
+
+// chunk size of STDIN mode: max_mmap, src/rzip.c:875-894
+int64_t stdin_chunk(const mrz_control *ctl, int to_stdout) {
+    const int64_t page = ctl->page_size > 0 ? ctl->page_size : 4096;
+    int64_t max_mmap = page_floor(ctl->ramsize / (to_stdout ? 6 : 3), page);
+    const int64_t max_chunk = ctl->window ? ctl->window * kChunkUnit : ctl->ramsize / 3 * 2;
+    return max_mmap < max_chunk ? max_mmap : max_chunk;
+}
+
+int run_file(const mrz_control *ctl, const Reader &rd, int64_t n, Out &out, mrz_stats *stats, uint8_t *md5_out) {
+    int rc = check_control(ctl);
+    if (rc || n < 0) return MRZ_E_ARG;
+    const int64_t max_chunk = mrz_plan(ctl, n, nullptr);
+    FileSource src(rd, n, max_chunk);
+    return run_chunks(ctl, src, 0, n, max_chunk < n ? max_chunk : n, out, stats, md5_out);
+}
+
+int run_stdin(const mrz_control *ctl, const Reader &rd, int to_stdout, Out &out, mrz_stats *stats, uint8_t *md5_out) {
+    int rc = check_control(ctl);
+    if (rc) return rc;
+    if (ctl->unlimited) return MRZ_E_ARG;  // -U takes the window from the file size, which STDIN does not have
+    const int64_t mm = stdin_chunk(ctl, to_stdout);
+    if (mm <= 0) return MRZ_E_ARG;
+    StdinSource src(rd, mm);
+    return run_chunks(ctl, src, to_stdout ? 2 : 1, 0, mm, out, stats, md5_out);
+}
+
+int vec_to_malloc(std::vector<uint8_t> &buf, void **out, int64_t *out_len) {
+    void *p = malloc(buf.size() ? buf.size() : 1);
+    if (!p) return MRZ_E_NOMEM;
+    memcpy(p, buf.data(), buf.size());
+    *out = p;
+    *out_len = (int64_t)buf.size();
     return MRZ_OK;
 }
 
@@ -323,43 +519,70 @@ extern "C" void mrz_free(void *p) { free(p); }
 extern "C" int mrz_rzip_buffer(const mrz_control *ctl, const void *in, int64_t n, void **out, int64_t *out_len,
                                mrz_stats *stats, uint8_t *md5_out) {
     if (!out || !out_len || (n > 0 && !in)) return MRZ_E_ARG;
-    std::vector<uint8_t> buf;
-    const int rc = run_file(ctl, (const uint8_t *)in, n, buf, stats, md5_out);
-    if (rc) return rc;
-    void *p = malloc(buf.size() ? buf.size() : 1);
-    if (!p) return MRZ_E_NOMEM;
-    memcpy(p, buf.data(), buf.size());
-    *out = p;
-    *out_len = (int64_t)buf.size();
-    return MRZ_OK;
+    try {
+        std::vector<uint8_t> buf;
+        Reader rd;
+        rd.mem = (const uint8_t *)in;
+        rd.mem_n = n;
+        Out o;
+        o.vec = &buf;
+        const int rc = run_file(ctl, rd, n, o, stats, md5_out);
+        if (rc) return rc;
+        return vec_to_malloc(buf, out, out_len);
+    } catch (const std::bad_alloc &) {
+        return MRZ_E_NOMEM;
+    }
+}
+
+extern "C" int mrz_rzip_stream_buffer(const mrz_control *ctl, const void *in, int64_t n, int to_stdout, void **out,
+                                      int64_t *out_len, mrz_stats *stats, uint8_t *md5_out) {
+    if (!out || !out_len || (n > 0 && !in)) return MRZ_E_ARG;
+    try {
+        std::vector<uint8_t> buf;
+        Reader rd;
+        rd.mem = (const uint8_t *)in;
+        rd.mem_n = n;
+        Out o;
+        o.vec = &buf;
+        const int rc = run_stdin(ctl, rd, to_stdout, o, stats, md5_out);
+        if (rc) return rc;
+        return vec_to_malloc(buf, out, out_len);
+    } catch (const std::bad_alloc &) {
+        return MRZ_E_NOMEM;
+    }
+}
+
+extern "C" int mrz_rzip_stream(const mrz_control *ctl, int fd_in, int fd_out, int to_stdout, mrz_stats *stats) {
+    try {
+        Reader rd;
+        rd.fd = fd_in;
+        Out o;
+        o.fd = fd_out;
+        return run_stdin(ctl, rd, to_stdout, o, stats, nullptr);
+    } catch (const std::bad_alloc &) {
+        return MRZ_E_NOMEM;
+    }
 }
 
 extern "C" int mrz_rzip_fd(const mrz_control *ctl, int fd_in, int fd_out, mrz_stats *stats) {
-    // read the whole input (the reference mmaps it, src/rzip.c:956)
-    std::vector<uint8_t> in;
-    uint8_t tmp[1 << 16];
-    for (;;) {
-        const ssize_t r = read(fd_in, tmp, sizeof(tmp));
-        if (r < 0) {
-            if (errno == EINTR) continue;
-            return MRZ_E_ARG;
-        }
-        if (r == 0) break;
-        in.insert(in.end(), tmp, tmp + r);
+    // a regular file is compressed as a FILE (size from fstat, src/rzip.c:864-866), anything else -- a pipe, a
+    // terminal -- the way the reference compresses STDIN; the output counts as STDOUT when it cannot seek
+    struct stat sb;
+    if (fstat(fd_in, &sb)) return MRZ_E_ARG;
+    const bool out_seeks = lseek(fd_out, 0, SEEK_CUR) != (off_t)-1;
+    if (!S_ISREG(sb.st_mode)) return mrz_rzip_stream(ctl, fd_in, fd_out, out_seeks ? 0 : 1, stats);
+    if (!out_seeks) return MRZ_E_ARG;  // file -> STDOUT keeps the output in a temporary buffer upstream: not mirrored
+    try {
+        const off_t at = lseek(fd_in, 0, SEEK_CUR);
+        const int64_t n = (int64_t)sb.st_size - (at > 0 ? (int64_t)at : 0);
+        Reader rd;
+        rd.fd = fd_in;
+        Out o;
+        o.fd = fd_out;
+        return run_file(ctl, rd, n < 0 ? 0 : n, o, stats, nullptr);
+    } catch (const std::bad_alloc &) {
+        return MRZ_E_NOMEM;
     }
-    std::vector<uint8_t> buf;
-    const int rc = run_file(ctl, in.data(), (int64_t)in.size(), buf, stats, nullptr);
-    if (rc) return rc;
-    size_t off = 0;
-    while (off < buf.size()) {
-        const ssize_t w = write(fd_out, buf.data() + off, buf.size() - off);
-        if (w < 0) {
-            if (errno == EINTR) continue;
-            return MRZ_E_ARG;
-        }
-        off += (size_t)w;
-    }
-    return MRZ_OK;
 }
 
 // ---- back-end hand-off pipeline -------------------------------------------------
@@ -537,18 +760,18 @@ int gather_stream(const uint8_t *mrz, int64_t n, int64_t initial_pos, int64_t he
         if (ctype != 3) return MRZ_E_UNSUPPORTED;
         if (c_len != u_len || c_len < 0) return MRZ_E_CORRUPT;
         const int64_t pay = at + 1 + 3 * cb;
-        if (pay + c_len > n) return MRZ_E_CORRUPT;
+        if (c_len > n - pay) return MRZ_E_CORRUPT;  // (compared without adding: a length field may be 2^63 - 1)
         dst.insert(dst.end(), mrz + pay, mrz + pay + c_len);
         if (pay + c_len > *end_max) *end_max = pay + c_len;
         if (!next) return MRZ_OK;
-        if (next < 0 || initial_pos + next <= at) return MRZ_E_CORRUPT;  // chains only run forward
+        if (next < 0 || next > n - initial_pos || initial_pos + next <= at) return MRZ_E_CORRUPT;  // chains only run forward
         at = initial_pos + next;
     }
 }
 
 }  // namespace
 
-extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void **out, int64_t *out_len) {
+static int runzip_buffer_impl(int device, const void *mrz_v, int64_t n, void **out, int64_t *out_len) {
     if (!mrz_v || !out || !out_len) return MRZ_E_ARG;
     const uint8_t *mrz = (const uint8_t *)mrz_v;
     if (n < 20 || memcmp(mrz, "MRZI", 4)) return MRZ_E_CORRUPT;  // read_magic, src/mrzip.c:225-321
@@ -556,7 +779,10 @@ extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void 
     const int64_t expected = peek_le(mrz + 6, 8);
     const int hash_code = mrz[14];
     if (hash_code != 0 && hash_code != 1) return MRZ_E_UNSUPPORTED;  // MD5 (default) or CRC only
-    uint8_t *res = (uint8_t *)malloc((size_t)(expected > 0 ? expected : 1));
+    // an archive written to STDOUT in several chunks carries no size (src/mrzip.c:137-140): grow chunk by chunk
+    const bool size_known = expected > 0;
+    int64_t cap = size_known ? expected : 0;
+    uint8_t *res = (uint8_t *)malloc((size_t)(cap > 0 ? cap : 1));
     if (!res) return MRZ_E_NOMEM;
     mrz_ctx *ctx = nullptr;
     int rc = mrz_open(&ctx, device, 7, 0);
@@ -572,7 +798,8 @@ extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void 
             rc = MRZ_E_CORRUPT;
             break;
         }
-        at += 2 + cb;  // chunk_bytes, eof, chunk size
+        at += 2 + cb;  // chunk_bytes, eof, chunk size (the field is chunk_bytes wide: a chunk below one page does
+                       // not fit its own size there, src/stream.c:779-780,1224 -- so it is not used for sizing)
         const int64_t initial_pos = at;
         int64_t end_max = initial_pos + 2 * (1 + 3 * cb);
         s0.clear();
@@ -580,10 +807,41 @@ extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void 
         rc = gather_stream(mrz, n, initial_pos, initial_pos, cb, s0, &end_max);
         if (!rc) rc = gather_stream(mrz, n, initial_pos, initial_pos + 1 + 3 * cb, cb, s1, &end_max);
         if (rc) break;
+        if (!size_known) {
+            // bytes this chunk decodes to: the lengths of its records (host side: 3 or 3 + cb bytes each)
+            int64_t need = 0, i = 0;
+            const int64_t n0 = (int64_t)s0.size();
+            bool ended = false;
+            while (i + 3 <= n0) {
+                const int64_t len = s0[(size_t)i + 1] | (int64_t)s0[(size_t)i + 2] << 8;
+                if (s0[(size_t)i] == 0) {
+                    if (len == 0) {
+                        ended = true;
+                        break;
+                    }
+                    i += 3;
+                } else
+                    i += 3 + cb;
+                need += len;
+            }
+            if (!ended) {
+                rc = MRZ_E_CORRUPT;
+                break;
+            }
+            if (total + need > cap) {
+                uint8_t *r2 = (uint8_t *)realloc(res, (size_t)(total + need > 0 ? total + need : 1));
+                if (!r2) {
+                    rc = MRZ_E_NOMEM;
+                    break;
+                }
+                res = r2;
+                cap = total + need;
+            }
+        }
         int64_t got = 0;
         uint32_t crc_calc = 0, crc_stored = 0;
         rc = mrz_runzip_chunk(ctx, s0.data(), (int64_t)s0.size(), s1.data(), (int64_t)s1.size(), MRZ_MEM_HOST, cb,
-                              res + total, MRZ_MEM_HOST, expected - total, &got, &crc_calc, &crc_stored);
+                              res + total, MRZ_MEM_HOST, cap - total, &got, &crc_calc, &crc_stored);
         if (rc == MRZ_E_ARG) rc = MRZ_E_CORRUPT;  // more output than the header promised
         if (rc) break;
         if (!hash_code && crc_calc != crc_stored) {  // "Bad checksum", src/runzip.c:317-320 (only without a hash)
@@ -595,7 +853,7 @@ extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void 
         if (eof) break;
     }
     if (ctx) mrz_close(ctx);
-    if (!rc && total != expected) rc = MRZ_E_CORRUPT;
+    if (!rc && size_known && total != expected) rc = MRZ_E_CORRUPT;
     if (!rc && hash_code == 1) {  // src/runzip.c:384-412
         uint8_t d[16];
         Md5 h;
@@ -610,4 +868,14 @@ extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void 
     *out = res;
     *out_len = total;
     return MRZ_OK;
+}
+
+extern "C" int mrz_runzip_buffer(int device, const void *mrz_v, int64_t n, void **out, int64_t *out_len) {
+    try {
+        return runzip_buffer_impl(device, mrz_v, n, out, out_len);
+    } catch (const std::bad_alloc &) {  // the header promises that the library never takes the host process down
+        return MRZ_E_NOMEM;
+    } catch (const std::length_error &) {
+        return MRZ_E_CORRUPT;
+    }
 }

@@ -15,9 +15,10 @@
 #define MRZ_WAVE_SYNC() (void)__ballot(1)
 #endif
 
-#ifndef MRZ_SEQ_WAVES
-#define MRZ_SEQ_WAVES 8   // waves of the sequencer workgroup = 64-lane slices of a wide batch
-#endif
+#ifndef MRZ_WIDE_WAVES
+#define MRZ_WIDE_WAVES 8  // waves of the wide engine's workgroup = 64-lane slices of a wide batch
+#endif                    // (the CPU emulator build takes 2: 512 fibers per barrier are slow, the logic is the same)
+#define MRZ_SEQ_WAVES MRZ_WIDE_WAVES
 #define MRZ_SEQ_THREADS (64 * MRZ_SEQ_WAVES)
 #ifndef MRZ_HELPER_WAVES
 #define MRZ_HELPER_WAVES 3  // waves of a helper workgroup that compare (the others leave at once)

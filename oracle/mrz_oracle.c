@@ -852,6 +852,80 @@ int mrzo_compress(const mrzo_params *prm, const uint8_t *in, int64_t n, mrzo_buf
     return rc;
 }
 
+/* `mrzip -n` reading STDIN (src/rzip.c:700-732 mmap_stdin, :915-1061 the chunk loop with STDIN set, src/util.c:156-164
+ * setup_ram).  What differs from a file: the size is not known, so every chunk is max_mmap = min(page-rounded maxram,
+ * max_chunk) bytes (maxram = ramsize / 3, or ramsize / 6 when the output goes to STDOUT too) until read() returns 0;
+ * the chunk in which that happens is shrunk and carries the eof flag -- when the input length is a multiple of the
+ * chunk size that is one more, EMPTY chunk; the stream block size is fixed at the first open_stream_out from the bytes
+ * read so far (src/stream.c:797-914 with control->st_size = first chunk); and the size field of the magic header is the
+ * total only if it is known when the header is written: at the end for a file (src/mrzip.c:1132), but at the first
+ * block of the first chunk for STDOUT (src/stream.c:1202-1205, write_magic :137-140: only `if (control->eof)`).
+ * `in`/`n` stand for what read() delivers.  Parity of this mode is pinned by reading only: the survey's golden vectors
+ * are file -> file runs. */
+int mrzo_compress_stream(const mrzo_params *prm, const uint8_t *in, int64_t n, int to_stdout, mrzo_buf *out,
+                         mrzo_stats *stats, uint8_t md5_out[16], int *nchunks_out) {
+    const int64_t page = prm->page_size ? prm->page_size : 4096;
+    if (prm->unlimited) return -3; /* -U takes the window from the file size: 0 for STDIN */
+    const int64_t maxram = prm->ramsize / (to_stdout ? 6 : 3);
+    int64_t max_mmap = page_floor(maxram, page);
+    const int64_t max_chunk = prm->window ? prm->window * CHUNK_UNIT : prm->ramsize / 3 * 2;
+    if (max_mmap > max_chunk) max_mmap = max_chunk;
+    mrzo_matcher *m = mrzo_matcher_new(prm->level);
+    if (!m) return -1;
+    sink_t k;
+    memset(&k, 0, sizeof(k));
+    k.out = out;
+    uint8_t mg[20] = { 0 };
+    int rc = buf_put(out, mg, 20) ? -1 : 0;
+    int64_t pos = 0, st_size = 0;
+    int eof = 0, nch = 0;
+    int64_t magic_size = 0;
+    mrzo_buf s0 = { 0, 0, 0 }, s1 = { 0, 0, 0 };
+    while (!rc && !eof) {
+        /* mmap_stdin: fill the chunk; a read that returns 0 ends the input */
+        int64_t csz = max_mmap;
+        if (n - pos < csz) { /* the read after the last byte returns 0 */
+            csz = n - pos;
+            eof = 1;
+        }
+        st_size += csz;
+        if (!nch) { /* first open_stream_out: src/stream.c:803-914 with NO_COMPRESS, one thread */
+            const int64_t chunk_limit = csz < page ? page : csz;
+            int64_t limit = maxram;
+            if (st_size > 0 && st_size < limit)
+                limit = st_size > STREAM_MIN ? st_size : STREAM_MIN;
+            else if (limit > chunk_limit)
+                limit = chunk_limit;
+            k.bufsize = page_ceil(limit, page);
+            if (to_stdout && eof) magic_size = st_size; /* write_magic at the first block: size known only at eof */
+        }
+        s0.len = s1.len = 0;
+        const int cb = mrzo_chunk_bytes(csz);
+        rc = mrzo_rzip_chunk(m, in + pos, csz, cb, &s0, &s1, NULL);
+        if (!rc) rc = sink_chunk(&k, csz, cb, eof, page, s0.p, s0.len, s1.p, s1.len);
+        pos += csz;
+        nch++;
+    }
+    mrzo_buf_free(&s0);
+    mrzo_buf_free(&s1);
+    mrzo_buf_free(&k.sbuf[0]);
+    mrzo_buf_free(&k.sbuf[1]);
+    if (!rc) {
+        uint8_t md5[16];
+        mrzo_md5 h;
+        mrzo_md5_init(&h);
+        mrzo_md5_update(&h, in, n);
+        mrzo_md5_final(&h, md5);
+        if (md5_out) memcpy(md5_out, md5, 16);
+        if (buf_put(out, md5, 16)) rc = -1;
+        if (!rc) fill_magic(out->p, prm, to_stdout ? magic_size : st_size);
+    }
+    if (stats) *stats = m->st;
+    if (nchunks_out) *nchunks_out = nch;
+    mrzo_matcher_free(m);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ */
 /* decoder (CTYPE_NONE only)                                            */
 

@@ -128,6 +128,12 @@ typedef struct {
 int mrzo_compress(const mrzo_params *prm, const uint8_t *in, int64_t n, mrzo_buf *out, mrzo_stats *stats,
                   uint8_t md5_out[16]);
 
+/* the same for input read from STDIN (src/rzip.c:700-732,915-1061; src/util.c:156-164): chunks of maxram bytes until
+ * read() returns 0, eof flag on the chunk that saw it (an empty one when the length is a multiple of the chunk size),
+ * stream block size from the first chunk, magic size field per src/mrzip.c:137-140.  to_stdout: output to STDOUT too. */
+int mrzo_compress_stream(const mrzo_params *prm, const uint8_t *in, int64_t n, int to_stdout, mrzo_buf *out,
+                         mrzo_stats *stats, uint8_t md5_out[16], int *nchunks_out);
+
 /* Chunking / sizing rules alone (src/rzip.c:875-894, src/util.c:156-176,
  * src/stream.c:797-914 for -n).  Returns max_chunk; *stream_bufsize gets the
  * per-stream block size for a file of st_size bytes. */

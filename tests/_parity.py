@@ -47,6 +47,63 @@ def check_file(lib, oracle, data, level=7, **kw):
     return got
 
 
+def check_stream(lib, oracle, data, to_stdout, ramsize, level=7):
+    """The STDIN form of rzip_fd's chunk loop (mrz_rzip_stream_buffer) vs the oracle's restatement: archive bytes,
+    counters, MD5; both decoders give the input back (an archive written to STDOUT in several chunks carries no size)."""
+    want, wstats, wmd5, nch = oracle.compress_stream(data, to_stdout=to_stdout, level=level, ramsize=ramsize)
+    got, gstats, gmd5 = m.rzip_stream_buffer(data, to_stdout=to_stdout, level=level, ramsize=ramsize, lib=lib)
+    assert gmd5 == wmd5 == hashlib.md5(data).digest()
+    assert gstats.as_dict() == wstats
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+    size_field = int.from_bytes(got[6:14], "little")
+    assert size_field == (len(data) if (not to_stdout or nch == 1) else 0)
+    assert m.runzip_buffer(got, lib=lib) == data
+    if size_field or not data:
+        rc, back = oracle.decompress(got)
+        assert rc == 0 and back == data
+    return got, nch
+
+
+def check_fd(lib, oracle, data, use_pipe, ramsize, tmp_path, level=7):
+    """mrz_rzip_fd on real descriptors: a regular file (FILE form) or a pipe (STDIN form) into a file."""
+    import os
+    import threading
+    outp = os.path.join(str(tmp_path), "out.mrz")
+    fd_out = os.open(outp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+    try:
+        if use_pipe:
+            r, w = os.pipe()
+
+            def feed():
+                with os.fdopen(w, "wb") as f:
+                    for a in range(0, len(data), 37000):  # ragged writes: read() returns short counts
+                        f.write(data[a:a + 37000])
+            t = threading.Thread(target=feed)
+            t.start()
+            try:
+                m.rzip_fd(r, fd_out, level=level, ramsize=ramsize, lib=lib)
+            finally:
+                t.join()
+                os.close(r)
+            want = oracle.compress_stream(data, to_stdout=False, level=level, ramsize=ramsize)[0]
+        else:
+            inp = os.path.join(str(tmp_path), "in.bin")
+            with open(inp, "wb") as f:
+                f.write(data)
+            fd_in = os.open(inp, os.O_RDONLY)
+            try:
+                m.rzip_fd(fd_in, fd_out, level=level, ramsize=ramsize, lib=lib)
+            finally:
+                os.close(fd_in)
+            want = oracle.compress(data, level=level, ramsize=ramsize)[0]
+    finally:
+        os.close(fd_out)
+    with open(outp, "rb") as f:
+        got = f.read()
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+    return got
+
+
 def _blocks_of_archive(mrz):
     """(stream, payload) of every block of a -n archive in FILE order = the reference's flush order
     (src/stream.c:1199-1293): walks the chunks, finds every block header by following both chains."""

@@ -53,6 +53,9 @@ class Oracle:
         L.mrzo_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int64]
         L.mrzo_compress.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(Buf),
                                     ctypes.POINTER(OStats), ctypes.c_char_p]
+        L.mrzo_compress_stream.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_int64, ctypes.c_int,
+                                           ctypes.POINTER(Buf), ctypes.POINTER(OStats), ctypes.c_char_p,
+                                           ctypes.POINTER(ctypes.c_int)]
         L.mrzo_decompress.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(Buf)]
         L.mrzo_frame.argtypes = [ctypes.POINTER(Params), ctypes.c_int64, ctypes.POINTER(ChunkStreams), ctypes.c_int,
                                  ctypes.c_char_p, ctypes.POINTER(Buf)]
@@ -106,6 +109,16 @@ class Oracle:
         rc = self.L.mrzo_compress(ctypes.byref(prm), data, len(data), ctypes.byref(out), ctypes.byref(st), md5)
         assert rc == 0, rc
         return self._take(self.L, out), st.as_dict(), md5.raw
+
+    def compress_stream(self, data, to_stdout=False, level=7, window=0, ramsize=60 << 30):
+        """`mrzip -n` reading STDIN: returns (archive, stats, md5, number of chunks)."""
+        prm = Params(level, window, 0, ramsize, 4096)
+        out, st, md5 = Buf(), OStats(), ctypes.create_string_buffer(16)
+        nch = ctypes.c_int(0)
+        rc = self.L.mrzo_compress_stream(ctypes.byref(prm), data, len(data), 1 if to_stdout else 0, ctypes.byref(out),
+                                         ctypes.byref(st), md5, ctypes.byref(nch))
+        assert rc == 0, rc
+        return self._take(self.L, out), st.as_dict(), md5.raw, nch.value
 
     def decompress(self, mrz):
         out = Buf()

@@ -172,3 +172,33 @@ def test_backend_handoff_pipeline(emu_lib, oracle):
     # a callback error aborts the run and comes back
     with pytest.raises(m.MrzError):
         m.rzip_pipeline(data, lambda info, payload: -6, lib=emu_lib, ramsize=3 * 16384 // 2 + 3000)
+
+
+@pytest.mark.parametrize("to_stdout", [False, True])
+def test_stdin_chunking(emu_lib, oracle, to_stdout):
+    """SURVEY a-11: mmap_stdin / the STDIN chunk loop (src/rzip.c:700-732,915-1061, src/util.c:156-164).  ramsize is
+    pinned so small that the input spans several chunks: maxram = ramsize / 3 (/ 6 towards STDOUT)."""
+    ram = 6 * 8192  # chunks of 16 KiB (8 KiB towards STDOUT)
+    chunk = ram // (6 if to_stdout else 3)
+    text = _util.zipf_text(3 * chunk + 777, seed=21)
+    for data in (b"", text[:100], text[:chunk - 1], text[:chunk], text[:chunk + 1], text[:2 * chunk], text):
+        got, nch = _parity.check_stream(emu_lib, oracle, data, to_stdout, ram)
+        # a length that is a multiple of the chunk size ends in one more, EMPTY chunk carrying the eof flag
+        assert nch == len(data) // chunk + 1
+
+
+def test_rzip_fd_on_a_pipe_and_on_a_file(emu_lib, oracle, tmp_path):
+    data = _util.rep64k(5, seed=3, period=4096) + _util.zipf_text(50000, seed=5)
+    _parity.check_fd(emu_lib, oracle, data, use_pipe=True, ramsize=3 * 16384, tmp_path=tmp_path)
+    _parity.check_fd(emu_lib, oracle, data, use_pipe=False, ramsize=3 * 16384, tmp_path=tmp_path)
+
+
+def test_corrupt_archive_with_huge_length_field(emu_lib):
+    """A block length of 2^63 - 1 in an 8-byte-wide chunk must be rejected, not overflow a bounds check."""
+    hdr = bytearray(b"MRZI" + bytes([0, 9]) + (100).to_bytes(8, "little") + bytes([1, 0, 0, 0, 0x77, 0]))
+    chunk = bytes([8, 1]) + (4096).to_bytes(8, "little")
+    head = lambda c, u, nx: bytes([3]) + c.to_bytes(8, "little") + u.to_bytes(8, "little") + nx.to_bytes(8, "little")
+    big = (1 << 63) - 1
+    body = head(0, 0, 50) + head(0, 0, 0) + head(big, big, 0)
+    with pytest.raises(m.MrzError):
+        m.runzip_buffer(bytes(hdr) + chunk + body + bytes(64), lib=emu_lib)

@@ -341,3 +341,86 @@ def test_rs_encoder(gpu_lib, oracle):
         d = _util.zipf_text(2 * burst + 77, seed=5)
         t = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
         assert ctx.rs_encode(t) == oracle.rs_encode(d)
+
+
+# ---- round 2: full-size bit-exactness, both sequencer engines, the STDIN form ---------------------------------
+
+def _sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def _exact_vs_oracle(gpu_lib, oracle, data, victim_round=0):
+    """streams (sha256), CRC, the seven counters, victim_round, final mask and hash_count -- all equal."""
+    want = oracle.rzip_chunk(data, level=7, victim_round=victim_round)
+    with m.RzipContext(lib=gpu_lib, max_chunk=len(data)) as ctx:
+        ctx.victim_round = victim_round
+        res, s0, s1 = ctx.rzip_chunk(data)
+        assert (_sha(s0), _sha(s1)) == (_sha(want["s0"]), _sha(want["s1"]))
+        assert res.crc32 == want["crc"] and res.stats.as_dict() == want["stats"]
+        assert ctx.victim_round == want["victim_round"]
+        assert res.min_mask == want["min_mask"] and res.hash_count == want["hash_count"]
+        return ctx.timings()
+
+
+def test_bench_config_10gib_bit_exact_vs_oracle(gpu_lib, oracle):
+    """BASELINE configs[1] at FULL size against the oracle (which takes ~5 s for it): both streams, the counters
+    and the chained victim_round, not only a round trip."""
+    data = w.rep64k_device(163840, "cuda").cpu().numpy().tobytes()
+    t = _exact_vs_oracle(gpu_lib, oracle, data)
+    assert t.n_narrow > 0  # the regime hint sent the stream to the narrow engine
+
+
+def test_text_100m_bit_exact_vs_oracle(gpu_lib, oracle):
+    """S1 text-100M (the shape of BASELINE configs[0]) against the oracle."""
+    _exact_vs_oracle(gpu_lib, oracle, w.zipf_text(100_000_000))
+
+
+def test_tar_like_1gib_bit_exact_vs_oracle(gpu_lib, oracle):
+    """1 GiB of the S3 tar mix (text and noise members, exact duplicates) against the oracle."""
+    parts, total, seed = [], 0, 11
+    while total < (1 << 30):
+        p = w.tar_like(64 << 20, seed=seed)
+        parts.append(p)
+        total += len(p)
+        seed += 1
+    # later blocks repeat earlier ones now and then: long matches at a distance of hundreds of MiB
+    data = b"".join(parts[:6] + [parts[1]] + parts[6:12] + [parts[3]] + parts[12:])[: 1 << 30]
+    _exact_vs_oracle(gpu_lib, oracle, data)
+
+
+@pytest.mark.parametrize("engine", ["wide", "narrow"])
+def test_both_engines_pinned(gpu_lib, oracle, engine, monkeypatch):
+    """Every shape through each of the two sequencer kernels alone (MRZ_SEQ_ENGINE pins the per-segment choice)."""
+    monkeypatch.setenv("MRZ_SEQ_ENGINE", engine)
+    _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(12 << 20, seed=3), table=True)
+    _parity.check_chunk(gpu_lib, oracle, _util.xorshift_noise(24 << 20, seed=5), table=True)
+    _parity.check_chunk(gpu_lib, oracle, _util.tar_like(8 << 20, seed=7), table=True, victim_round=9)
+    _parity.check_chunk(gpu_lib, oracle, _util.rep64k(512, seed=1234), table=True)
+    _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(3 << 20, seed=8), level=1, table=True)
+    _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(3 << 20, seed=8), level=9, table=True)
+
+
+def test_engines_alternate_within_one_chunk(gpu_lib, oracle):
+    """Text, then a long stretch of one match after another, then noise: the per-segment choice changes engine in the
+    middle of the chunk, the two kernels continue each other through the matcher state."""
+    data = _util.zipf_text(40 << 20, seed=2) + _util.rep64k(3072, seed=1234) + _util.xorshift_noise(40 << 20, seed=4)
+    t = _exact_vs_oracle(gpu_lib, oracle, data)
+    assert 0 < t.n_narrow < t.n_segments
+
+
+@pytest.mark.parametrize("to_stdout", [False, True])
+def test_stdin_chunking(gpu_lib, oracle, to_stdout):
+    """SURVEY a-11 / BASELINE configs[4] (scaled): the STDIN form of the chunk loop, several chunks incl. the empty
+    eof chunk of an input whose length is a multiple of the chunk size."""
+    ram = 6 << 20
+    chunk = ram // (6 if to_stdout else 3)
+    text = _util.tar_like(3 * chunk + 12345, seed=21)
+    for data in (b"", text[:chunk - 1], text[:chunk], text[:2 * chunk], text):
+        got, nch = _parity.check_stream(gpu_lib, oracle, data, to_stdout, ram)
+        assert nch == len(data) // chunk + 1
+
+
+def test_rzip_fd_on_a_pipe_and_on_a_file(gpu_lib, oracle, tmp_path):
+    data = _util.rep64k(40, seed=3) + _util.zipf_text(3 << 20, seed=5)
+    _parity.check_fd(gpu_lib, oracle, data, use_pipe=True, ramsize=3 << 20, tmp_path=tmp_path)
+    _parity.check_fd(gpu_lib, oracle, data, use_pipe=False, ramsize=3 << 20, tmp_path=tmp_path)
