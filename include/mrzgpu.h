@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRZ_ABI_VERSION 1
+#define MRZ_ABI_VERSION 2
 
 enum {
     MRZ_OK = 0,
@@ -109,6 +109,22 @@ int mrz_set_profiling(mrz_ctx *ctx, int enable);
  * the library sets 8 at load time unless the variable is already set.) */
 int mrz_set_farm_helpers(mrz_ctx *ctx, int n);
 int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out);
+
+/* Progress of the chunk in flight (within-chunk hand-off to the back-end: the reference flushes a stream buffer the
+ * moment it fills DURING hash_search, src/rzip.c:197-211 -> flush_buffer src/stream.c:1347).  mrz_rzip_chunk calls
+ * `fn` on the calling thread every time a segment of the chunk has been sequenced and once more when the whole chunk
+ * has: the first n_events matches of the chunk are final, and so is every byte before last_match (literal or
+ * matched).  Inside `fn` mrz_fetch_events may be called; the device keeps working on the segments already queued.
+ * A non-zero return aborts the chunk with MRZ_E_STATE.  fn = NULL switches it off. */
+typedef struct {
+    int64_t p;   /* position of the match in the chunk */
+    int64_t ofs; /* position it copies from (distance = p - ofs) */
+    int64_t len; /* before splitting into 0xFFFF pieces (put_match, src/rzip.c:179-194) */
+} mrz_match;
+typedef int (*mrz_progress_fn)(void *user, int64_t n_events, int64_t last_match, int chunk_done);
+int mrz_set_progress(mrz_ctx *ctx, mrz_progress_fn fn, void *user);
+/* copies matches [first, first + count) of the chunk in flight (or of the last chunk) to host memory */
+int mrz_fetch_events(mrz_ctx *ctx, int64_t first, int64_t count, mrz_match *host_dst);
 
 /* ---- the rzip stage ---------------------------------------------------- */
 

@@ -29,6 +29,9 @@ typedef struct {
     int64_t page_size;          /* control->page_size (4096) */
     int hash_code;              /* control->hash_code; only 1 (MD5, the default) is supported */
     int device;                 /* HIP device ordinal */
+    int lz4_test;               /* FLAG_THRESHOLD / LZ4_TEST (-T switches it off, src/main.c:499-510): the pipeline
+                                 * asks the LZ4 compressibility gate about every block */
+    int threshold;              /* control->threshold, per cent (default 100, src/mrzip.c:1376) */
 } mrz_control;
 
 /* As `mrzip -n -L<level> [-w|-U] -m<ramsize>` would write it.  fd_in a regular file: the FILE form of the chunk loop
@@ -61,13 +64,18 @@ void mrz_free(void *p);
  * src/stream.c:797-914 for -n): returns max_chunk, *stream_bufsize optional */
 int64_t mrz_plan(const mrz_control *control, int64_t st_size, int64_t *stream_bufsize);
 
-/* ---- back-end hand-off ------------------------------------------------
+/* ---- back-end hand-off --------------------------------------------
  * What the reference's sink does between rzip and the back-end codecs: every stream buffer that fills
- * (stream_bufsize bytes, src/stream.c:878-914) is handed over as one block (flush_buffer :1307-1349 ->
- * compthread :1115-1305) and the output keeps flush order.  mrz_rzip_pipeline runs the GPU rzip stage
- * over the chunks of `in` and calls `fn` once per block, in that order, on a consumer thread that
- * overlaps the GPU work on the next chunk; `fn` is where a back-end would compress (and frame) the block.
- * A non-zero return of `fn` aborts the run and is returned. */
+ * (stream_bufsize bytes, src/stream.c:878-914) is handed over as one block the moment it fills, DURING
+ * hash_search (write_sbstream src/rzip.c:197-211 -> flush_buffer src/stream.c:1307-1349 -> compthread
+ * :1115-1305); the output keeps flush order; a back-end that honours LZ4_TEST first asks lz4_compresses
+ * (src/stream.c:1685-1733, called from lzma/zpaq/bzip3_compress_buf :249,167,124) whether the block is worth
+ * compressing.  mrz_rzip_pipeline runs the GPU rzip stage over the chunks of `in`; as soon as a segment of a
+ * chunk has been sequenced the host encodes the records that have become final (put_match / put_literal,
+ * src/rzip.c:179-227) and cuts blocks; a consumer thread runs the LZ4 gate on the device for every block
+ * (control->lz4_test) and then calls `fn` -- once per block, in flush order, while the GPU is still working on
+ * the rest of the same chunk.  `fn` is where a back-end would compress (and frame) the block.  A non-zero
+ * return of `fn` aborts the run and is returned. */
 typedef struct {
     int chunk_index;      /* 0, 1, ... */
     int stream;           /* 0 = control records, 1 = literal bytes */
@@ -75,6 +83,10 @@ typedef struct {
     int eof;              /* this is the file's last chunk (src/rzip.c:1049) */
     int64_t chunk_size;
     int first_of_chunk;   /* first block of the chunk: the chunk header precedes it in the file */
+    int lz4_verdict;      /* lz4_compresses' answer for this block: 0 = does not compress (store it), 1..100 = per
+                           * cent of its size; -1 = not asked (control->lz4_test == 0, or fewer than 64 bytes:
+                           * compthread only compresses blocks of >= 64 bytes, src/stream.c:1147) */
+    int64_t input_final;  /* bytes of the chunk that were final (sequenced) when the block was cut */
 } mrz_block_info;
 typedef int (*mrz_block_fn)(void *user, const mrz_block_info *info, const uint8_t *payload, int64_t len);
 int mrz_rzip_pipeline(const mrz_control *control, const void *in, int64_t n, mrz_block_fn fn, void *user,

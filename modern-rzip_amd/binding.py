@@ -38,13 +38,15 @@ class Control(ctypes.Structure):
     """The rzip_control fields rzip_fd reads for `mrzip -n` (include/mrzgpu_host.h)."""
     _fields_ = [("rzip_compression_level", ctypes.c_int), ("compression_level", ctypes.c_int),
                 ("window", ctypes.c_int64), ("unlimited", ctypes.c_int), ("ramsize", ctypes.c_int64),
-                ("page_size", ctypes.c_int64), ("hash_code", ctypes.c_int), ("device", ctypes.c_int)]
+                ("page_size", ctypes.c_int64), ("hash_code", ctypes.c_int), ("device", ctypes.c_int),
+                ("lz4_test", ctypes.c_int), ("threshold", ctypes.c_int)]
 
 
 class BlockInfo(ctypes.Structure):
     """mrz_block_info (include/mrzgpu_host.h)."""
     _fields_ = [("chunk_index", ctypes.c_int), ("stream", ctypes.c_int), ("chunk_bytes", ctypes.c_int),
-                ("eof", ctypes.c_int), ("chunk_size", ctypes.c_int64), ("first_of_chunk", ctypes.c_int)]
+                ("eof", ctypes.c_int), ("chunk_size", ctypes.c_int64), ("first_of_chunk", ctypes.c_int),
+                ("lz4_verdict", ctypes.c_int), ("input_final", ctypes.c_int64)]
 
 
 BLOCK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockInfo), ctypes.POINTER(ctypes.c_uint8),
@@ -376,11 +378,15 @@ def runzip_buffer(mrz, device=0, lib=None):
         lib.mrz_free(out)
 
 
-def rzip_pipeline(data, on_block, level=7, window=0, unlimited=False, ramsize=60 << 30, device=0, lib=None):
+def rzip_pipeline(data, on_block, level=7, window=0, unlimited=False, ramsize=60 << 30, device=0, lib=None,
+                  lz4_test=False, threshold=100):
     """mrz_rzip_pipeline: the GPU rzip stage over the chunks of `data`; `on_block(info_dict, payload_bytes)` is
-    called once per stream block in the reference's flush order (return None/0 to go on).  Returns (Stats, md5)."""
+    called once per stream block in the reference's flush order, while the rest of the chunk is still being
+    sequenced (return None/0 to go on).  lz4_test: every block is put to the LZ4 gate first (info["lz4_verdict"]).
+    Returns (Stats, md5)."""
     lib = lib or load_library()
-    ctl = Control(level, level, window, 1 if unlimited else 0, ramsize, 4096, 1, device)
+    ctl = Control(level, level, window, 1 if unlimited else 0, ramsize, 4096, 1, device, 1 if lz4_test else 0,
+                  threshold)
     ptr, n, where, keep = _as_ptr(data)
     if where != MEM_HOST:
         raise MrzError("rzip_pipeline takes host memory")
@@ -388,7 +394,8 @@ def rzip_pipeline(data, on_block, level=7, window=0, unlimited=False, ramsize=60
     def trampoline(user, info, payload, length):
         i = info.contents
         d = dict(chunk_index=i.chunk_index, stream=i.stream, chunk_bytes=i.chunk_bytes, eof=i.eof,
-                 chunk_size=i.chunk_size, first_of_chunk=i.first_of_chunk)
+                 chunk_size=i.chunk_size, first_of_chunk=i.first_of_chunk, lz4_verdict=i.lz4_verdict,
+                 input_final=i.input_final)
         return int(on_block(d, ctypes.string_at(payload, length)) or 0)
 
     fn = BLOCK_FN(trampoline)

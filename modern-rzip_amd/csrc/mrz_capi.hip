@@ -99,6 +99,7 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     if (ctx->lz4_scratch) hipFree(ctx->lz4_scratch);
     if (ctx->b2_scratch) hipFree(ctx->b2_scratch);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -144,7 +145,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_index, &cap, 256); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tab, &cap, ctx->nslots); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_state, &cap, 1); }
-    if (!rc && hipHostMalloc((void **)&ctx->h_pos, 64) != hipSuccess) rc = MRZ_E_NOMEM;
+    if (!rc && hipHostMalloc((void **)&ctx->h_pos, 256) != hipSuccess) rc = MRZ_E_NOMEM;
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tags, &cap, MRZ_SEG_POSITIONS); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_bitmap, &cap, MRZ_SEG_POSITIONS / 16 + 64); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_totals, &cap, 1); }
@@ -202,6 +203,26 @@ extern "C" int mrz_synchronize(mrz_ctx *ctx) {
 extern "C" int mrz_set_profiling(mrz_ctx *ctx, int enable) {
     if (!ctx) return MRZ_E_ARG;
     ctx->profiling = enable ? 1 : 0;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_set_progress(mrz_ctx *ctx, mrz_progress_fn fn, void *user) {
+    if (!ctx) return MRZ_E_ARG;
+    ctx->progress_fn = fn;
+    ctx->progress_user = user;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_fetch_events(mrz_ctx *ctx, int64_t first, int64_t count, mrz_match *host_dst) {
+    if (!ctx || first < 0 || count < 0 || (count > 0 && !host_dst)) return MRZ_E_ARG;
+    if (first + count > ctx->events_final) return MRZ_E_STATE;
+    if (!count) return MRZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    static_assert(sizeof(mrz_match) == sizeof(mrz_event), "mrz_match mirrors mrz_event");
+    HIPCHK(ctx, hipMemcpyAsync(host_dst, ctx->d_events + first, (size_t)count * sizeof(mrz_event), hipMemcpyDeviceToHost,
+                               ctx->copy_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     return MRZ_OK;
 }
 
@@ -351,7 +372,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     // segment that has just finished: a segment that an emitted match has already covered completely (a stream
     // that repeats itself: one match of gigabytes) needs no tag scan and no sequencer launch at all.
     int64_t *h_pos = ctx->h_pos;  // pinned; written by the copies below: p, hint_positions, hint_events, hint_matched
-    h_pos[0] = h_pos[1] = h_pos[2] = h_pos[3] = 0;
+    for (int k = 0; k < 8; k++) h_pos[k] = 0;  // [4] last_match, [5] n_events of the latest finished launch
+    ctx->events_final = 0;
     int engine_pin = 0, n_narrow = 0;
     {
         const char *e = getenv("MRZ_SEQ_ENGINE");
@@ -371,6 +393,16 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         if (seg_len > MRZ_SEG_POSITIONS) seg_len = MRZ_SEG_POSITIONS;
         if (launched >= MRZ_SEG_AHEAD) {
             STEP(hipEventSynchronize(seg_ev[launched % MRZ_SEG_AHEAD]));  // the launch MRZ_SEG_AHEAD back is done
+            if (herr == hipSuccess && ctx->progress_fn) {
+                // what that launch (or a later one that has finished meanwhile) has left is final
+                const int64_t ne = *(volatile int64_t *)(h_pos + 5), lm = *(volatile int64_t *)(h_pos + 4);
+                ctx->events_final = ne;
+                if (ctx->progress_fn(ctx->progress_user, ne, lm, 0)) {
+                    hipStreamSynchronize(s);
+                    rc = MRZ_E_STATE;
+                    break;
+                }
+            }
             // positions are only ever visited in order: the last candidate of this segment is seg_start + seg_len - 1
             if (herr == hipSuccess && *(volatile int64_t *)h_pos >= seg_start + seg_len - 1) continue;
         }
@@ -400,6 +432,10 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         if (narrow) n_narrow++;
         STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         STEP(hipMemcpyAsync(h_pos + 1, &ctx->d_state->hint_positions, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (ctx->progress_fn) {
+            STEP(hipMemcpyAsync(h_pos + 4, &ctx->d_state->last_match, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            STEP(hipMemcpyAsync(h_pos + 5, &ctx->d_state->n_events, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        }
         if (launched < 2 && !engine_pin) STEP(hipStreamSynchronize(s));
         STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));
         launched++;
@@ -409,7 +445,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     STEP(hipMemcpyAsync(&crc, ctx->d_crc_out, 4, hipMemcpyDeviceToHost, s));
     STEP(hipStreamSynchronize(s));
     if (herr == hipSuccess) {
-        if (hs.error || !hs.finished) {
+        if (!rc && (hs.error || !hs.finished)) {
             fprintf(stderr,
                     "libmrzgpu: sequencer stopped abnormally: error=%d finished=%d p=%lld end=%lld events=%lld/%lld "
                     "count=%lld min_mask=%lld\n",
@@ -418,6 +454,10 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
             rc = MRZ_E_OVERFLOW;
         }
         E = hs.n_events;
+        if (!rc && ctx->progress_fn) {
+            ctx->events_final = E;
+            if (ctx->progress_fn(ctx->progress_user, E, hs.last_match, 1)) rc = MRZ_E_STATE;
+        }
     }
 
     // record encoding

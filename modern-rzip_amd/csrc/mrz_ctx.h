@@ -64,6 +64,10 @@ struct mrz_ctx {
     void *b2_scratch;
     int64_t b2_scratch_cap;
     hipStream_t side_stream;  // low-priority stream for the co-resident checksum kernels
+    hipStream_t copy_stream;  // non-blocking stream for copies that must not wait for the queued segments
+    mrz_progress_fn progress_fn;
+    void *progress_user;
+    int64_t events_final;     // matches of the chunk in flight that are final (mrz_fetch_events bound)
 };
 
 #define HIPCHK(ctx, expr)                     \

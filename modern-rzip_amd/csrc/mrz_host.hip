@@ -593,25 +593,32 @@ extern "C" int mrz_rzip_fd(const mrz_control *ctl, int fd_in, int fd_out, mrz_st
 // where a back-end codec would compress the block.
 namespace {
 
-struct ChunkJob {
-    int index, cb, eof;
-    int64_t chunk_size;
-    std::vector<uint8_t> s0, s1;
+struct Block {
+    mrz_block_info info;
+    std::vector<uint8_t> payload;
 };
 
-struct BlockCutter {  // write_stream / flush_buffer without the file: every full buffer is one callback
-    mrz_block_fn fn;
-    void *user;
-    int64_t bufsize;
+// write_stream / flush_buffer without the file: every full stream buffer becomes one Block for the consumer
+struct BlockCutter {
+    int64_t bufsize = 0;
     mrz_block_info info;
     std::vector<uint8_t> sbuf[2];
-    int rc = 0;
+    std::mutex *mu = nullptr;
+    std::condition_variable *cv = nullptr;
+    std::deque<Block *> *queue = nullptr;
+    const int *abort_rc = nullptr;
     void flush(int s) {
-        if (rc) return;
-        info.stream = s;
-        rc = fn(user, &info, sbuf[s].data(), (int64_t)sbuf[s].size());
+        Block *b = new Block;
+        b->info = info;
+        b->info.stream = s;
+        b->payload.swap(sbuf[s]);
         info.first_of_chunk = 0;
-        sbuf[s].clear();
+        {
+            std::unique_lock<std::mutex> lk(*mu);
+            cv->wait(lk, [&] { return queue->size() < 4 || *abort_rc; });  // back-pressure: a few blocks in flight
+            queue->push_back(b);
+        }
+        cv->notify_all();
     }
     void write(int s, const uint8_t *p, int64_t n) {
         while (n) {
@@ -625,13 +632,70 @@ struct BlockCutter {  // write_stream / flush_buffer without the file: every ful
     }
 };
 
+// put_literal (src/rzip.c:213-227): per <= 0xFFFF piece a {00, len} header on stream 0, then its bytes on stream 1
+void put_literal(BlockCutter &w, const uint8_t *buf, int64_t from, int64_t to) {
+    do {
+        int64_t len = to - from;
+        if (len > 0xFFFF) len = 0xFFFF;
+        const uint8_t hdr[3] = { 0, (uint8_t)len, (uint8_t)(len >> 8) };
+        w.write(0, hdr, 3);
+        if (len) w.write(1, buf + from, len);
+        from += len;
+    } while (to > from);
+}
+
+// put_match (src/rzip.c:179-194): {01, len, dist} per <= 0xFFFF piece, dist = p - offset
+void put_match(BlockCutter &w, int cb, int64_t p, int64_t ofs, int64_t len) {
+    const int64_t dist = p - ofs;
+    do {
+        const int64_t n = len > 0xFFFF ? 0xFFFF : len;
+        uint8_t rec[3 + 8] = { 1, (uint8_t)n, (uint8_t)(n >> 8) };
+        for (int i = 0; i < cb; i++) rec[3 + i] = (uint8_t)((uint64_t)dist >> (8 * i));
+        w.write(0, rec, 3 + cb);
+        len -= n;
+    } while (len);
+}
+
+// state of the chunk in flight, driven by mrz_rzip_chunk's progress calls
+struct ChunkFeed {
+    mrz_ctx *ctx;
+    const uint8_t *buf;
+    int64_t n;
+    int cb;
+    BlockCutter *cut;
+    int64_t ev_done = 0, lit_from = 0;  // matches encoded so far; end of the last encoded match
+    std::vector<mrz_match> ev;
+    const int *abort_rc;
+};
+
+int chunk_progress(void *user, int64_t n_events, int64_t last_match, int chunk_done) {
+    ChunkFeed *f = (ChunkFeed *)user;
+    if (*f->abort_rc) return 1;
+    try {
+        if (n_events > f->ev_done) {
+            const int64_t cnt = n_events - f->ev_done;
+            f->ev.resize((size_t)cnt);
+            if (mrz_fetch_events(f->ctx, f->ev_done, cnt, f->ev.data())) return 1;
+            f->cut->info.input_final = last_match;
+            for (int64_t i = 0; i < cnt; i++) {  // hash_search's emit, src/rzip.c:593-595
+                const mrz_match &e = f->ev[(size_t)i];
+                if (f->lit_from < e.p) put_literal(*f->cut, f->buf, f->lit_from, e.p);
+                put_match(*f->cut, f->cb, e.p, e.ofs, e.len);
+                f->lit_from = e.p + e.len;
+            }
+            f->ev_done = n_events;
+        }
+        (void)chunk_done;
+    } catch (const std::bad_alloc &) {
+        return 1;
+    }
+    return 0;
+}
+
 }  // namespace
 
-extern "C" int mrz_rzip_pipeline(const mrz_control *ctl, const void *in_v, int64_t n, mrz_block_fn fn, void *user,
-                                 mrz_stats *stats, uint8_t *md5_out) {
-    if (!ctl || !fn || n < 0 || (n > 0 && !in_v)) return MRZ_E_ARG;
-    if (ctl->rzip_compression_level < 1 || ctl->rzip_compression_level > 9) return MRZ_E_ARG;
-    const uint8_t *in = (const uint8_t *)in_v;
+static int rzip_pipeline_impl(const mrz_control *ctl, const uint8_t *in, int64_t n, mrz_block_fn fn, void *user,
+                              mrz_stats *stats, uint8_t *md5_out) {
     int64_t bufsize = 0;
     const int64_t max_chunk = mrz_plan(ctl, n, &bufsize);
 
@@ -642,86 +706,103 @@ extern "C" int mrz_rzip_pipeline(const mrz_control *ctl, const void *in_v, int64
         h.finish(md5);
     });
 
-    // consumer: cuts finished chunks into blocks, in order, while the GPU works on the next chunk
+    // consumer: the LZ4 gate (on its own ctx / stream) and the caller's function, block by block, in flush order
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<ChunkJob *> queue;
+    std::deque<Block *> queue;
     bool producer_done = false;
     int consumer_rc = 0;
+    mrz_ctx *gate = nullptr;
+    int rc = MRZ_OK;
+    if (ctl->lz4_test) rc = mrz_open(&gate, ctl->device, ctl->rzip_compression_level, 0);
     std::thread consumer([&]() {
-        BlockCutter cut;
-        cut.fn = fn;
-        cut.user = user;
-        cut.bufsize = bufsize;
         for (;;) {
-            ChunkJob *job = nullptr;
+            Block *b = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !queue.empty() || producer_done; });
                 if (queue.empty()) break;
-                job = queue.front();
+                b = queue.front();
                 queue.pop_front();
             }
             cv.notify_all();
             if (!consumer_rc) {
-                cut.info.chunk_index = job->index;
-                cut.info.chunk_bytes = job->cb;
-                cut.info.eof = job->eof;
-                cut.info.chunk_size = job->chunk_size;
-                cut.info.first_of_chunk = 1;
-                int rc = mrz_replay_records(cut, job->cb, job->s0.data(), (int64_t)job->s0.size(), job->s1.data(),
-                                            (int64_t)job->s1.size());
-                if (!rc) {
-                    cut.flush(0);  // close_stream_out flushes both streams, even when empty (src/stream.c:1623-1648)
-                    cut.flush(1);
-                    rc = cut.rc;
+                b->info.lz4_verdict = -1;
+                int r = 0;
+                if (gate && (int64_t)b->payload.size() >= 64) {  // compthread: `c_len >= 64`, src/stream.c:1147
+                    int verdict = 0;
+                    r = mrz_lz4_compresses(gate, b->payload.data(), (int64_t)b->payload.size(), MRZ_MEM_HOST,
+                                           ctl->threshold > 0 ? ctl->threshold : 100, &verdict);
+                    b->info.lz4_verdict = verdict;
                 }
-                if (rc) consumer_rc = rc;
+                if (!r) r = fn(user, &b->info, b->payload.data(), (int64_t)b->payload.size());
+                if (r) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    consumer_rc = r;
+                }
+                if (r) cv.notify_all();
             }
-            delete job;
+            delete b;
         }
     });
 
     mrz_ctx *ctx = nullptr;
-    int rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, max_chunk < n ? max_chunk : n);
+    if (!rc) rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, max_chunk < n ? max_chunk : n);
     mrz_stats total;
     memset(&total, 0, sizeof(total));
     int64_t victim_round = 0, left = n, pos = 0;
     int pass = 0;
-    while (!rc && (!pass || left > 0)) {  // chunk loop, src/rzip.c:915-1061
-        const int64_t csz = max_chunk < left ? max_chunk : left;
-        const int cb = mrz_chunk_bytes(csz);
-        mrz_chunk_result res;
-        rc = mrz_rzip_chunk(ctx, in + pos, csz, MRZ_MEM_HOST, cb, &victim_round, &res);
-        if (rc) break;
-        ChunkJob *job = new ChunkJob;
-        job->index = pass;
-        job->cb = cb;
-        job->eof = csz == left;
-        job->chunk_size = csz;
-        job->s0.resize((size_t)res.s0_len);
-        job->s1.resize((size_t)res.s1_len);
-        rc = mrz_fetch_streams(ctx, job->s0.data(), job->s1.data());
-        if (rc) {
-            delete job;
-            break;
+    BlockCutter cut;
+    cut.bufsize = bufsize;
+    cut.mu = &mu;
+    cut.cv = &cv;
+    cut.queue = &queue;
+    cut.abort_rc = &consumer_rc;
+    try {
+        while (!rc && (!pass || left > 0)) {  // chunk loop, src/rzip.c:915-1061
+            const int64_t csz = max_chunk < left ? max_chunk : left;
+            const int cb = mrz_chunk_bytes(csz);
+            memset(&cut.info, 0, sizeof(cut.info));
+            cut.info.chunk_index = pass;
+            cut.info.chunk_bytes = cb;
+            cut.info.eof = csz == left;
+            cut.info.chunk_size = csz;
+            cut.info.first_of_chunk = 1;
+            cut.info.lz4_verdict = -1;
+            ChunkFeed feed;
+            feed.ctx = ctx;
+            feed.buf = in + pos;
+            feed.n = csz;
+            feed.cb = cb;
+            feed.cut = &cut;
+            feed.abort_rc = &consumer_rc;
+            mrz_set_progress(ctx, chunk_progress, &feed);
+            mrz_chunk_result res;
+            rc = mrz_rzip_chunk(ctx, in + pos, csz, MRZ_MEM_HOST, cb, &victim_round, &res);
+            mrz_set_progress(ctx, nullptr, nullptr);
+            if (rc) break;
+            // the tail of hash_search (src/rzip.c:619,664-665): trailing literal, terminator, CRC (most significant
+            // byte first); then close_stream_out flushes both streams, even when empty (src/stream.c:1623-1648)
+            cut.info.input_final = csz;
+            if (feed.lit_from < csz) put_literal(cut, in + pos, feed.lit_from, csz);
+            const uint8_t term[7] = { 0, 0, 0, (uint8_t)(res.crc32 >> 24), (uint8_t)(res.crc32 >> 16),
+                                      (uint8_t)(res.crc32 >> 8), (uint8_t)res.crc32 };
+            cut.write(0, term, 7);
+            cut.flush(0);
+            cut.flush(1);
+            total.inserts += res.stats.inserts;
+            total.literals += res.stats.literals;
+            total.literal_bytes += res.stats.literal_bytes;
+            total.matches += res.stats.matches;
+            total.match_bytes += res.stats.match_bytes;
+            total.tag_hits += res.stats.tag_hits;
+            total.tag_misses += res.stats.tag_misses;
+            pos += csz;
+            left -= csz;
+            pass++;
         }
-        total.inserts += res.stats.inserts;
-        total.literals += res.stats.literals;
-        total.literal_bytes += res.stats.literal_bytes;
-        total.matches += res.stats.matches;
-        total.match_bytes += res.stats.match_bytes;
-        total.tag_hits += res.stats.tag_hits;
-        total.tag_misses += res.stats.tag_misses;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return queue.size() < 2; });  // at most two finished chunks wait for the back-end
-            queue.push_back(job);
-        }
-        cv.notify_all();
-        pos += csz;
-        left -= csz;
-        pass++;
+    } catch (const std::bad_alloc &) {
+        rc = MRZ_E_NOMEM;
     }
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -730,12 +811,25 @@ extern "C" int mrz_rzip_pipeline(const mrz_control *ctl, const void *in_v, int64
     cv.notify_all();
     consumer.join();
     hasher.join();
+    for (Block *b : queue) delete b;
     if (ctx) mrz_close(ctx);
-    if (!rc) rc = consumer_rc;
+    if (gate) mrz_close(gate);
+    if (consumer_rc) rc = consumer_rc;
     if (rc) return rc;
     if (stats) *stats = total;
     if (md5_out) memcpy(md5_out, md5, 16);
     return MRZ_OK;
+}
+
+extern "C" int mrz_rzip_pipeline(const mrz_control *ctl, const void *in_v, int64_t n, mrz_block_fn fn, void *user,
+                                 mrz_stats *stats, uint8_t *md5_out) {
+    if (!ctl || !fn || n < 0 || (n > 0 && !in_v)) return MRZ_E_ARG;
+    if (ctl->rzip_compression_level < 1 || ctl->rzip_compression_level > 9) return MRZ_E_ARG;
+    try {
+        return rzip_pipeline_impl(ctl, (const uint8_t *)in_v, n, fn, user, stats, md5_out);
+    } catch (const std::bad_alloc &) {
+        return MRZ_E_NOMEM;
+    }
 }
 
 // ---- decompress side: `mrzip -d` of a -n archive (runzip_fd, src/runzip.c:332-437) -----------------

@@ -138,7 +138,8 @@ def _blocks_of_archive(mrz):
 
 def check_pipeline(lib, oracle, data, level=7, **kw):
     """mrz_rzip_pipeline hands over exactly the blocks of the reference-identical archive, in file order."""
-    want, wstats, wmd5 = oracle.compress(data, level=level, **kw)
+    okw = {k: v for k, v in kw.items() if k not in ("lz4_test", "threshold")}
+    want, wstats, wmd5 = oracle.compress(data, level=level, **okw)
     got = []
     st, md5 = m.rzip_pipeline(data, lambda info, payload: got.append((info, payload)) and None, level=level, lib=lib, **kw)
     assert md5 == wmd5 and st.as_dict() == wstats
@@ -147,4 +148,10 @@ def check_pipeline(lib, oracle, data, level=7, **kw):
     chunks = sorted({i["chunk_index"] for i, _ in got})
     assert chunks == list(range(len(chunks)))
     assert [i["eof"] for i, _ in got if i["first_of_chunk"]] == [0] * (len(chunks) - 1) + [1]
+    if kw.get("lz4_test"):
+        # the gate's verdict for every block = lz4_compresses of the oracle on the same bytes (blocks of >= 64 bytes)
+        for i, p in got:
+            assert i["lz4_verdict"] == (oracle.lz4_compresses(p, kw.get("threshold", 100)) if len(p) >= 64 else -1)
+    else:
+        assert all(i["lz4_verdict"] == -1 for i, _ in got)
     return got

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -120,6 +121,10 @@ static void fiber_main() {
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    // one kernel at a time: the scheduler's state is global, and host threads of the library (the pipeline's
+    // consumer runs the LZ4 gate while the producer sequences) may launch concurrently
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> launch_lock(launch_mu);
     const unsigned nthreads = block.x * block.y * block.z;
     const unsigned nwaves = (nthreads + 63) / 64;
     static std::vector<Fiber> fibers;

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.mrz_abi_version() == 1
+    assert lib.mrz_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device():
@@ -53,5 +53,5 @@ def test_host_control_layout_matches_header():
     # mrz_control in include/mrzgpu_host.h <-> binding.Control
     assert [f[0] for f in m.Control._fields_] == [
         "rzip_compression_level", "compression_level", "window", "unlimited", "ramsize", "page_size", "hash_code",
-        "device"]
+        "device", "lz4_test", "threshold"]
     assert ctypes.sizeof(m.ChunkResult) == 8 + 8 + 4 + 4 + 8 + 8 + 56 + 24

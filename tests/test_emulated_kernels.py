@@ -169,6 +169,8 @@ def test_backend_handoff_pipeline(emu_lib, oracle):
     got = _parity.check_pipeline(emu_lib, oracle, data, ramsize=3 * 16384 // 2 + 3000)
     assert max(i["chunk_index"] for i, _ in got) >= 2
     _parity.check_pipeline(emu_lib, oracle, b"")
+    # the LZ4 gate wired in: a verdict per block (compthread -> lzma_compress_buf -> lz4_compresses)
+    _parity.check_pipeline(emu_lib, oracle, data[:60000], ramsize=3 * 16384 // 2 + 3000, lz4_test=True, threshold=90)
     # a callback error aborts the run and comes back
     with pytest.raises(m.MrzError):
         m.rzip_pipeline(data, lambda info, payload: -6, lib=emu_lib, ramsize=3 * 16384 // 2 + 3000)

@@ -29,7 +29,7 @@ def inputs():
 def test_native_library_is_loaded(gpu_lib):
     import torch
     assert torch.cuda.is_available()
-    assert gpu_lib.mrz_abi_version() == 1
+    assert gpu_lib.mrz_abi_version() == 2
     assert os.path.basename(m.lib_path()) == "libmrzgpu.so"
     with open("/proc/self/maps") as f:
         assert "libmrzgpu.so" in f.read()
@@ -153,6 +153,24 @@ def test_backend_handoff_pipeline(gpu_lib, oracle):
     """mrz_rzip_pipeline: blocks of stream_bufsize bytes in the reference's flush order, several per stream
     (24 MiB of literals against a 10 MiB buffer) and several chunks, GPU work overlapping the consumer."""
     _parity.check_pipeline(gpu_lib, oracle, _util.xorshift_noise(24 << 20, seed=17) + _util.rep64k(40, seed=3))
+    # the LZ4 gate wired in (default mode: compthread -> lzma_compress_buf -> lz4_compresses): a verdict per block
+    _parity.check_pipeline(gpu_lib, oracle, _util.tar_like(40 << 20, seed=9), ramsize=60 << 20, lz4_test=True)
+
+
+def test_pipeline_hands_blocks_over_before_the_chunk_is_done(gpu_lib, oracle):
+    """Within-chunk hand-off (write_sbstream -> flush_buffer during hash_search, src/rzip.c:197-211): on a ONE-chunk
+    input of several segments the first block reaches the consumer while later segments have not been sequenced."""
+    # every 1 MiB of noise is followed by a copy of itself: half of the input is literal bytes (stream 1 fills a
+    # 10 MiB block every 20 MiB of input), and a match is emitted every 2 MiB, so bytes become final as the segments
+    # go by (hash_search only writes literals when a match is emitted, src/rzip.c:593: match-free input has nothing to
+    # hand over before its end, in the reference as here).  6 segments of 16 Mi positions.
+    noise = _util.xorshift_noise(48 << 20, seed=23)
+    data = b"".join(noise[a:a + (1 << 20)] * 2 for a in range(0, len(noise), 1 << 20))
+    got = _parity.check_pipeline(gpu_lib, oracle, data, ramsize=30 << 20, unlimited=True)
+    assert {i["chunk_index"] for i, _ in got} == {0}
+    first = got[0][0]
+    assert first["input_final"] < len(data) // 2, first  # cut long before the chunk's last segment was launched
+    assert got[-1][0]["input_final"] == len(data)
     got = _parity.check_pipeline(gpu_lib, oracle, _util.rep64k(96, seed=13), ramsize=3 << 20)
     assert max(i["chunk_index"] for i, _ in got) >= 2
 
