@@ -126,6 +126,33 @@ int mrz_set_progress(mrz_ctx *ctx, mrz_progress_fn fn, void *user);
 /* copies matches [first, first + count) of the chunk in flight (or of the last chunk) to host memory */
 int mrz_fetch_events(mrz_ctx *ctx, int64_t first, int64_t count, mrz_match *host_dst);
 
+/* ---- one window over several GPUs (second row; BASELINE configs[3]) --------------------------
+ * What shards inside ONE chunk is the front end: every rank owns a contiguous byte range of the window (plus a
+ * 30-byte halo) and computes the tags of its positions (single_full_tag / next_tag, src/rzip.c:330-358) and the
+ * candidate bitmap for the mask the matcher has reached (:573); the exact matcher itself stays on one rank, which
+ * takes the segments' tags from their owners instead of scanning them.
+ *
+ * mrz_window_scan (any rank): tags and bitmap of positions [seg_start, seg_start + seg_len) of a chunk of chunk_n
+ * bytes, given the rank's bytes [range_start, range_start + range_len) -- which must reach 48 bytes past the
+ * segment's last position (30 for the tags, the rest because the kernel loads 16-byte pieces) or to the end of the
+ * chunk; seg_len a multiple of 4096 unless the segment is the chunk's last.  min_mask: the matcher's minimum_tag_mask as last heard of
+ * (an older, looser mask only makes the bitmap a superset, which the matcher re-checks); p_done: positions at or
+ * before it need no tags.  tags_out: seg_len x int64, bitmap_out: ceil(seg_len / 64) x uint64, host memory.
+ *
+ * mrz_set_tag_provider (the matcher's rank): mrz_rzip_chunk then calls `fn` for every segment it is about to
+ * sequence instead of scanning it; `fn` has to fill the two device buffers (seg_len x int64 tags, seg_len / 64
+ * words of bitmap; e.g. hipMemcpyAsync on `stream`, or a blocking copy) and return 0.  fn = NULL: scan locally.
+ * mrz_set_segment_positions: positions per segment launch (a multiple of 4096, at most the default of 16 Mi). */
+int mrz_window_scan(mrz_ctx *ctx, const void *range_bytes, int64_t range_len, int where, int64_t range_start,
+                    int64_t chunk_n, int64_t seg_start, int64_t seg_len, int64_t min_mask, int64_t p_done,
+                    int64_t *tags_out, uint64_t *bitmap_out);
+typedef int (*mrz_tag_provider_fn)(void *user, int64_t seg_index, int64_t seg_start, int64_t seg_len, int64_t min_mask,
+                                   int64_t p_done, int64_t *d_tags, uint64_t *d_bitmap, void *stream);
+int mrz_set_tag_provider(mrz_ctx *ctx, mrz_tag_provider_fn fn, void *user);
+int mrz_set_segment_positions(mrz_ctx *ctx, int64_t positions);
+/* host -> device copy on the ctx stream (what a tag provider without a HIP runtime of its own fills the buffers with) */
+int mrz_copy_to_device(mrz_ctx *ctx, void *dst_device, const void *src_host, int64_t n);
+
 /* ---- the rzip stage ---------------------------------------------------- */
 
 /* Replaces rzip_chunk -> hash_search (src/rzip.c:763-792,507-667) for one

@@ -34,6 +34,11 @@ class Timings(ctypes.Structure):
                 ("n_narrow", ctypes.c_int32)]
 
 
+# mrz_tag_provider_fn (include/mrzgpu.h)
+TAG_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+
+
 class Control(ctypes.Structure):
     """The rzip_control fields rzip_fd reads for `mrzip -n` (include/mrzgpu_host.h)."""
     _fields_ = [("rzip_compression_level", ctypes.c_int), ("compression_level", ctypes.c_int),
@@ -84,6 +89,11 @@ def load_library(path=None):
     lib.mrz_strerror.argtypes = [ci]
     lib.mrz_strerror.restype = ctypes.c_char_p
     lib.mrz_last_hip_error.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p)]
+    if hasattr(lib, "mrz_window_scan"):
+        lib.mrz_window_scan.argtypes = [vp, vp, i64, ci, i64, i64, i64, i64, i64, i64, vp, vp]
+        lib.mrz_set_tag_provider.argtypes = [vp, TAG_FN, vp]
+        lib.mrz_set_segment_positions.argtypes = [vp, i64]
+        lib.mrz_copy_to_device.argtypes = [vp, vp, vp, i64]
     lib.mrz_stream.argtypes = [vp]
     lib.mrz_stream.restype = vp
     lib.mrz_synchronize.argtypes = [vp]
@@ -172,6 +182,7 @@ class RzipContext:
         self.ctx = ctypes.c_void_p()
         _check(self.lib, self.lib.mrz_open(ctypes.byref(self.ctx), device, level, max_chunk))
         self.level = level
+        self.device = device
         self.victim_round = 0  # static victim_round of insert_hash (src/rzip.c:259)
 
     def close(self):
@@ -197,6 +208,41 @@ class RzipContext:
 
     def set_farm_helpers(self, n):
         _check(self.lib, self.lib.mrz_set_farm_helpers(self.ctx, n), self.ctx)
+
+    def set_segment_positions(self, positions):
+        _check(self.lib, self.lib.mrz_set_segment_positions(self.ctx, positions), self.ctx)
+
+    def window_scan(self, range_bytes, range_start, chunk_n, seg_start, seg_len, min_mask, p_done=0):
+        """mrz_window_scan: (tags, bitmap) of one segment from this rank's byte range, as bytes objects."""
+        ptr, n, where, keep = _as_ptr(range_bytes)
+        tags = ctypes.create_string_buffer(seg_len * 8)
+        bitmap = ctypes.create_string_buffer(((seg_len + 63) // 64) * 8)
+        _check(self.lib, self.lib.mrz_window_scan(self.ctx, ptr, n, where, range_start, chunk_n, seg_start, seg_len,
+                                                  min_mask, p_done, tags, bitmap), self.ctx)
+        return tags.raw, bitmap.raw
+
+    def set_tag_provider(self, provider):
+        """provider(seg_index, seg_start, seg_len, min_mask, p_done) -> (tags bytes, bitmap bytes), called by
+        rzip_chunk for every segment instead of the local tag scan; None switches back."""
+        if provider is None:
+            self._tag_cb = None
+            _check(self.lib, self.lib.mrz_set_tag_provider(self.ctx, ctypes.cast(None, TAG_FN), None), self.ctx)
+            return
+
+        def tramp(user, seg_index, seg_start, seg_len, min_mask, p_done, d_tags, d_bitmap, stream):
+            try:
+                tags, bitmap = provider(seg_index, seg_start, seg_len, min_mask, p_done)
+                if len(tags) != seg_len * 8 or len(bitmap) != ((seg_len + 63) // 64) * 8:
+                    return 1
+                if self.lib.mrz_copy_to_device(self.ctx, d_tags, tags, len(tags)):
+                    return 1
+                return 1 if self.lib.mrz_copy_to_device(self.ctx, d_bitmap, bitmap, len(bitmap)) else 0
+            except Exception:  # noqa: BLE001 -- must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._tag_cb = TAG_FN(tramp)
+        _check(self.lib, self.lib.mrz_set_tag_provider(self.ctx, self._tag_cb, None), self.ctx)
 
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.mrz_set_profiling(self.ctx, 1 if on else 0), self.ctx)

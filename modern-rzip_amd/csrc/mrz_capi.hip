@@ -122,6 +122,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     mrz_ctx *ctx = (mrz_ctx *)calloc(1, sizeof(mrz_ctx));
     if (!ctx) return MRZ_E_NOMEM;
     ctx->farm_helpers = -1;
+    ctx->seg_positions = MRZ_SEG_POSITIONS;
     ctx->farm_default = mrz_sequencer_default_helpers(device);
     ctx->device = device;
     ctx->level = level;
@@ -226,6 +227,59 @@ extern "C" int mrz_fetch_events(mrz_ctx *ctx, int64_t first, int64_t count, mrz_
     return MRZ_OK;
 }
 
+extern "C" int mrz_set_tag_provider(mrz_ctx *ctx, mrz_tag_provider_fn fn, void *user) {
+    if (!ctx) return MRZ_E_ARG;
+    ctx->tag_fn = fn;
+    ctx->tag_user = user;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_copy_to_device(mrz_ctx *ctx, void *dst_device, const void *src_host, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && (!dst_device || !src_host))) return MRZ_E_ARG;
+    if (!n) return MRZ_OK;
+    HIPCHK(ctx, hipMemcpyAsync(dst_device, src_host, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the source may be reused on return
+    return MRZ_OK;
+}
+
+extern "C" int mrz_set_segment_positions(mrz_ctx *ctx, int64_t positions) {
+    if (!ctx || positions < 4096 || positions > MRZ_SEG_POSITIONS || positions % 4096) return MRZ_E_ARG;
+    ctx->seg_positions = positions;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_window_scan(mrz_ctx *ctx, const void *range_bytes, int64_t range_len, int where, int64_t range_start,
+                               int64_t chunk_n, int64_t seg_start, int64_t seg_len, int64_t min_mask, int64_t p_done,
+                               int64_t *tags_out, uint64_t *bitmap_out) {
+    if (!ctx || !range_bytes || !tags_out || !bitmap_out || range_len <= 0 || range_start < 0 || chunk_n <= 0)
+        return MRZ_E_ARG;
+    if (seg_len <= 0 || seg_len > MRZ_SEG_POSITIONS || seg_start < range_start) return MRZ_E_ARG;
+    // the last position's 31-byte window must lie in the rank's bytes (or the chunk ends first)
+    const int64_t last_pos = seg_start + seg_len - 1;
+    // (the kernel stages whole 16-byte pieces: 48 bytes of halo keep every load inside the rank's bytes)
+    const int64_t need_end = last_pos + 48 < chunk_n ? last_pos + 48 : chunk_n;
+    if (need_end > range_start + range_len) return MRZ_E_ARG;
+    if (seg_len % 4096 && seg_start + seg_len + MRZ_MIN_MATCH <= chunk_n) return MRZ_E_ARG;  // whole tiles, or the chunk's tail
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint8_t *d_range = nullptr;
+    int rc = mrz_stage_input(ctx, range_bytes, range_len, where, &d_range);
+    if (rc) return rc;
+    mrz_seq_state hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.p = p_done;
+    hs.min_mask = min_mask;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
+    // the kernel indexes the chunk by absolute position: give it the pointer position 0 would have.  It stays
+    // inside [range_start, need_end + 16) of it; the staging buffer is padded by 64 bytes.
+    HIPCHK(ctx, mrz_launch_tagscan(s, d_range - range_start, chunk_n, seg_start, seg_len, ctx->d_index, ctx->d_state,
+                                   ctx->d_tags, ctx->d_bitmap));
+    HIPCHK(ctx, hipMemcpyAsync(tags_out, ctx->d_tags, (size_t)seg_len * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(bitmap_out, ctx->d_bitmap, (size_t)((seg_len + 63) / 64) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return MRZ_OK;
+}
+
 extern "C" int mrz_set_farm_helpers(mrz_ctx *ctx, int n) {
     if (!ctx) return MRZ_E_ARG;
     ctx->farm_helpers = n < 0 ? -1 : n;
@@ -311,7 +365,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     int nev = 0, evcap = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     const int64_t end = n - MRZ_MIN_MATCH;
-    const int64_t nseg = end > 0 ? (end + 1 + MRZ_SEG_POSITIONS - 1) / MRZ_SEG_POSITIONS : 0;
+    const int64_t SEGP = ctx->seg_positions;
+    const int64_t nseg = end > 0 ? (end + 1 + SEGP - 1) / SEGP : 0;
     if (ctx->profiling) {
         evcap = (int)(2 * nseg + 4);
         evs = (mrz_evpair *)calloc((size_t)evcap, sizeof(mrz_evpair));
@@ -372,7 +427,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     // segment that has just finished: a segment that an emitted match has already covered completely (a stream
     // that repeats itself: one match of gigabytes) needs no tag scan and no sequencer launch at all.
     int64_t *h_pos = ctx->h_pos;  // pinned; written by the copies below: p, hint_positions, hint_events, hint_matched
-    for (int k = 0; k < 8; k++) h_pos[k] = 0;  // [4] last_match, [5] n_events of the latest finished launch
+    for (int k = 0; k < 8; k++) h_pos[k] = 0;  // [4] last_match, [5] n_events, [6] min_mask of the latest finished launch
+    h_pos[6] = (1ll << ctx->initial_freq) - 1;
     ctx->events_final = 0;
     int engine_pin = 0, n_narrow = 0;
     {
@@ -388,9 +444,9 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     }
     int64_t launched = 0;
     for (int64_t sg = 0; sg < nseg && herr == hipSuccess; sg++) {
-        const int64_t seg_start = sg * MRZ_SEG_POSITIONS;
+        const int64_t seg_start = sg * SEGP;
         int64_t seg_len = end + 1 - seg_start;
-        if (seg_len > MRZ_SEG_POSITIONS) seg_len = MRZ_SEG_POSITIONS;
+        if (seg_len > SEGP) seg_len = SEGP;
         if (launched >= MRZ_SEG_AHEAD) {
             STEP(hipEventSynchronize(seg_ev[launched % MRZ_SEG_AHEAD]));  // the launch MRZ_SEG_AHEAD back is done
             if (herr == hipSuccess && ctx->progress_fn) {
@@ -407,8 +463,18 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
             if (herr == hipSuccess && *(volatile int64_t *)h_pos >= seg_start + seg_len - 1) continue;
         }
         PROF_BEGIN(0);
-        STEP(mrz_launch_tagscan(s, d_buf, n, seg_start, seg_len, ctx->d_index, ctx->d_state, ctx->d_tags,
-                                ctx->d_bitmap));
+        if (ctx->tag_fn) {
+            // window sharding: the segment's owner has scanned it (with the mask this rank had last reported)
+            if (herr == hipSuccess &&
+                ctx->tag_fn(ctx->tag_user, sg, seg_start, seg_len, *(volatile int64_t *)(h_pos + 6),
+                            *(volatile int64_t *)h_pos, ctx->d_tags, (uint64_t *)ctx->d_bitmap, (void *)s)) {
+                hipStreamSynchronize(s);
+                rc = MRZ_E_STATE;
+                break;
+            }
+        } else
+            STEP(mrz_launch_tagscan(s, d_buf, n, seg_start, seg_len, ctx->d_index, ctx->d_state, ctx->d_tags,
+                                    ctx->d_bitmap));
         PROF_END();
         // Which engine: the wide one (512 candidates per batch) unless the segments before were one long match after
         // another (>= 80 % of the positions a launch advanced over lay inside the matches it emitted): then the
@@ -432,6 +498,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         if (narrow) n_narrow++;
         STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         STEP(hipMemcpyAsync(h_pos + 1, &ctx->d_state->hint_positions, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (ctx->tag_fn) STEP(hipMemcpyAsync(h_pos + 6, &ctx->d_state->min_mask, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         if (ctx->progress_fn) {
             STEP(hipMemcpyAsync(h_pos + 4, &ctx->d_state->last_match, sizeof(int64_t), hipMemcpyDeviceToHost, s));
             STEP(hipMemcpyAsync(h_pos + 5, &ctx->d_state->n_events, sizeof(int64_t), hipMemcpyDeviceToHost, s));

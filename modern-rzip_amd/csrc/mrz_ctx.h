@@ -68,6 +68,9 @@ struct mrz_ctx {
     mrz_progress_fn progress_fn;
     void *progress_user;
     int64_t events_final;     // matches of the chunk in flight that are final (mrz_fetch_events bound)
+    int64_t seg_positions;    // positions per segment launch (MRZ_SEG_POSITIONS unless a test shrinks it)
+    mrz_tag_provider_fn tag_fn;  // window sharding: another rank scans the tags of a segment
+    void *tag_user;
 };
 
 #define HIPCHK(ctx, expr)                     \

@@ -51,8 +51,15 @@ def _worker(rank, world, port, q):
             return s0, s1, ctx.victim_round
 
         parts = shard.rzip_file_chunk_chain(data, max_chunk, rank, world, run, dist)
+        spec = shard.rzip_file_chunk_chain_speculative(data, max_chunk, rank, world, run, dist)
+        noise = _util.xorshift_noise(3 * max_chunk, seed=12)  # no evictions: victim_round never moves
+        spec_noise = shard.rzip_file_chunk_chain_speculative(noise, max_chunk, rank, world, run, dist)
         ctx.close()
         if rank == 0:
+            assert spec[0] == parts  # the same streams whether or not the predictions held
+            assert spec_noise[1] == 0  # ... and on a stream without evictions no chunk had to be run twice
+            want_n, _, _ = oracle.compress(noise, ramsize=ramsize)
+            assert oracle.frame(len(noise), spec_noise[0], hashlib.md5(noise).digest(), ramsize=ramsize) == want_n
             assert len(parts) == 3
             md5 = hashlib.md5(data).digest()
             got = oracle.frame(len(data), parts, md5, ramsize=ramsize)
@@ -69,6 +76,23 @@ def _worker(rank, world, port, q):
             crc = shard.chunk_crc_sharded(big, rank, world, c2.crc32, dist)
         if rank == 0:
             assert crc == zlib.crc32(big)
+        # (4) ONE window over the two ranks (BASELINE configs[3], scaled): every rank scans the tags of the segments in
+        # its byte range, rank 0 runs the exact matcher over them; streams identical to the single-process oracle
+        from modern_rzip_amd import workloads
+        win = workloads.stride_stream(8, 96 * 1024, seed=50)  # noise, every 4th segment repeats an earlier one
+        segp = 64 * 1024
+        ranges = shard.segment_ranges(len(win), world, segp)
+        off, size = ranges[rank]
+        mine = win[off:off + size + 48]  # own range + halo
+        with m.RzipContext(lib=lib, max_chunk=len(win)) as c3:
+            out = shard.rzip_chunk_window(c3, mine, off, len(win), rank, world, dist, segp, victim_round=5)
+            crc = shard.chunk_crc_sharded(win, rank, world, c3.crc32, dist)
+        if rank == 0:
+            res, s0, s1 = out
+            want = oracle.rzip_chunk(win, victim_round=5)
+            assert (s0, s1) == (want["s0"], want["s1"])
+            assert res.stats.as_dict() == want["stats"] and res.crc32 == want["crc"] == crc
+            assert res.stats.matches >= 2
         q.put((rank, "ok"))
     except BaseException as e:  # surface the failure in the parent
         q.put((rank, repr(e)))
@@ -114,3 +138,27 @@ def test_crc32_combine_and_ranges():
         assert len(r) == world and sum(n for _, n in r) == total
         assert all(o % 4096 == 0 or n == 0 for o, n in r)
         assert all(r[i][0] + r[i][1] == r[i + 1][0] or r[i + 1][1] == 0 for i in range(world - 1))
+
+
+def test_window_scan_of_ranges_equals_local_scan(emu_lib, oracle):
+    """The tag provider path on one process: segments scanned from byte ranges (with halo) give the same streams."""
+    import modern_rzip_amd as m
+    from modern_rzip_amd import shard, workloads
+    from tests import _util
+    data = _util.zipf_text(150000, seed=9) + workloads.stride_stream(4, 40000, seed=3)
+    segp = 32 * 1024
+    want = oracle.rzip_chunk(data)
+    with m.RzipContext(lib=emu_lib, max_chunk=len(data)) as ctx, m.RzipContext(lib=emu_lib, max_chunk=len(data)) as other:
+        ranges = shard.segment_ranges(len(data), 3, segp)
+        assert sum(n for _, n in ranges) == len(data) and all(o % segp == 0 for o, _ in ranges)
+
+        def provider(seg_index, seg_start, seg_len, min_mask, p_done):
+            r = max(i for i in range(3) if ranges[i][0] <= seg_start and ranges[i][1])
+            off, size = ranges[r]
+            return other.window_scan(data[off:off + size + 48], off, len(data), seg_start, seg_len, min_mask, p_done)
+
+        ctx.set_segment_positions(segp)
+        ctx.set_tag_provider(provider)
+        res, s0, s1 = ctx.rzip_chunk(data)
+        ctx.set_tag_provider(None)
+        assert (s0, s1) == (want["s0"], want["s1"]) and res.stats.as_dict() == want["stats"]
