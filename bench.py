@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- rzip-stage throughput of libmrzgpu on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--mode streams|window]
 
 A "step" is one pass of the rzip stage (mrz_rzip_chunk: tag scan -> sequencer ->
 record encoder, + CRC-32) over one chunk that is already resident in HBM.  The
@@ -10,15 +10,22 @@ with 64 KiB-period repeats (S2 "rep64k-10G"), one chunk (-m pinned
 so max_chunk >= file size).  With N > 1 every rank runs its own 10 GiB stream on
 its own GPU (chunks / files are independent units of the reference: N `mrzip`
 processes), so scaling is weak and there is no data-path collective.
+--mode window (N > 1) instead splits ONE window over the ranks: range-sharded tag
+scan, tags sent to rank 0 over RCCL, exact matcher on rank 0 (shard.rzip_chunk_window);
+strong scaling of a front end whose back end (the matcher) does not shard.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description):
 value = whole-job GiB/s of input consumed; roofline = algorithmic bytes
 (N + literal bytes + stream-0 bytes) over the measured time of the
 dominant kernel (the sequencer), against the 8 TB/s HBM peak; cpu_baseline = the
 oracle (bit-exact C restatement of the reference's single-threaded rzip stage)
-timed on a bounded prefix of the same stream on this host.
+timed on a bounded prefix of the same stream on this host, 8-byte and byte-wise
+match extension, and checked against a GPU run of the same prefix; shapes = the
+other workload shapes (text, noise, tar mix) on GPU and oracle, measured once,
+outside the timed region.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,26 +38,49 @@ GIB = 1 << 30
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(sample_bytes):
-    """Times the oracle's rzip stage (1 core) on the first sample_bytes of the workload."""
+def _oracle():
     import subprocess
-    from modern_rzip_amd import workloads
     from tests import _util
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
-    o = _util.Oracle(path)
+    return _util.Oracle(path)
+
+
+def _sha(b):
+    return hashlib.sha256(b).hexdigest()[:16]
+
+
+def cpu_baseline(ctx, sample_bytes):
+    """Times the oracle's rzip stage (1 core) on the first sample_bytes of the workload, with the 8-byte and the
+    byte-wise match extension, and checks that a GPU run of the same prefix gives the same two streams."""
+    from modern_rzip_amd import workloads
+    o = _oracle()
     data = workloads.rep64k(sample_bytes // 65536, seed=1234)
     t0 = time.perf_counter()
     r = o.rzip_chunk(data, level=7)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rb = o.rzip_chunk(data, level=7, bytewise=True)
+    dtb = time.perf_counter() - t0
+    ctx.victim_round = 0
+    t0 = time.perf_counter()
+    res, s0, s1 = ctx.rzip_chunk(data)
+    gdt = time.perf_counter() - t0
+    same = (s0, s1) == (r["s0"], r["s1"]) == (rb["s0"], rb["s1"]) and res.stats.as_dict() == r["stats"]
+    if not same:
+        raise SystemExit("cpu_baseline: the GPU streams of the prefix differ from the oracle's")
     return {"value": round(len(data) / GIB / dt, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
             "sample": f"first {len(data) / GIB:.2f} GiB of the same rep64k stream, oracle/liboracle.so "
                       f"mrzo_rzip_chunk (matcher + CRC32, no MD5), {dt:.1f} s",
+            "bytewise_value": round(len(data) / GIB / dtb, 5),
+            "bytewise_note": "the same with single_match_len's byte-at-a-time compare (src/rzip.c:378) instead of 8 bytes",
+            "gpu_same_prefix_GiBps": round(len(data) / GIB / gdt, 5),
+            "prefix_sha256": {"oracle_s0": _sha(r["s0"]), "gpu_s0": _sha(s0), "oracle_s1": _sha(r["s1"]), "gpu_s1": _sha(s1)},
             "matches": r["stats"]["matches"]}
 
 
-def pmc_traffic(nseg):
+def pmc_traffic():
     """HBM bytes per sequencer launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 +
     WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes); None if no summary is present."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -59,6 +89,31 @@ def pmc_traffic(nseg):
             return json.load(f)["sequencer_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def shape_line(ctx, name, data, oracle_sample=None):
+    """One workload shape: GPU GiB/s (one chunk, profiling events on), oracle GiB/s on the same bytes (or on a
+    prefix of them), the roofline fraction recomputed the same way as for the headline."""
+    o = _oracle()
+    ctx.victim_round = 0
+    ctx.rzip_chunk(data, fetch=False)  # warm
+    ctx.victim_round = 0
+    t0 = time.perf_counter()
+    res, _, _ = ctx.rzip_chunk(data, fetch=False)
+    dt = time.perf_counter() - t0
+    tm = ctx.timings()
+    sample = data if oracle_sample is None else data[:oracle_sample]
+    t0 = time.perf_counter()
+    o.rzip_chunk(sample, level=7)
+    odt = time.perf_counter() - t0
+    alg = len(data) + res.s1_len + res.s0_len
+    seq_s = tm.sequencer_ms / 1e3
+    return {"name": name, "bytes": len(data), "gpu_GiBps": round(len(data) / GIB / dt, 5),
+            "oracle_GiBps": round(len(sample) / GIB / odt, 5), "oracle_sample_bytes": len(sample),
+            "gpu_over_oracle": round((len(data) / dt) / (len(sample) / odt), 3),
+            "sequencer_ms": round(tm.sequencer_ms, 2), "launches": tm.n_segments, "narrow_launches": tm.n_narrow,
+            "roofline_frac": round(alg / seq_s / 1e9 / HBM_PEAK_GBPS, 6) if seq_s > 0 else None,
+            "matches": res.stats.matches}
 
 
 def main():
@@ -70,7 +125,11 @@ def main():
     ap.add_argument("--level", type=int, default=7)
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the other workload shapes (text, noise, tar mix)")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed GPU decode of the result")
+    ap.add_argument("--mode", default="streams", choices=["streams", "window"],
+                    help="streams: one independent stream per GPU (weak scaling); window: ONE window range-sharded over "
+                         "the GPUs, matcher on rank 0 (strong scaling of the front end)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the "
                     "multi-process path with several ranks on one GPU: ranks wrap around the visible devices)")
     args = ap.parse_args()
@@ -99,13 +158,16 @@ def main():
             dist.init_process_group(args.dist_backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    lib = m.load_library()
+
+    if args.mode == "window" and world > 1:
+        return window_mode(args, m, workloads, lib, dist, rank, world, dev_index)
 
     nper = int(args.gib * GIB) // 65536
     n = nper * 65536
     data = workloads.rep64k_device(nper, dev, seed=1234 + rank)  # every rank its own stream
     torch.cuda.synchronize()
 
-    lib = m.load_library()
     ctx = m.RzipContext(level=args.level, max_chunk=n, device=dev_index, lib=lib)
     ctx.set_profiling(True)
 
@@ -122,7 +184,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     seq_ms = tag_ms = enc_ms = crc_ms = 0.0
-    nseg = 0
+    nseg = nnarrow = 0
     for _ in range(args.steps):
         ctx.victim_round = 0  # each step = a fresh `mrzip` process on the same file
         res, _, _ = ctx.rzip_chunk(data, fetch=False)  # returns after the device work has completed
@@ -131,7 +193,7 @@ def main():
         tag_ms += t.tagscan_ms
         enc_ms += t.encode_ms
         crc_ms += t.crc_ms
-        nseg = t.n_segments
+        nseg, nnarrow = t.n_segments, t.n_narrow
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -177,11 +239,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"rep64k-{args.gib:g}G: mrzip -n -L{args.level}, {args.gib:g} GiB synthetic text with "
                                    f"64 KiB-period repeats (BASELINE configs[1]), one chunk per GPU, input resident in HBM",
-                       "level": args.level, "chunk_bytes_per_gpu": n, "streams": world},
-            "roofline": {"bound": "hbm", "kernel": "mrz_sequencer_kernel", "achieved": round(achieved, 3),
+                       "level": args.level, "chunk_bytes_per_gpu": n, "streams": world, "mode": "streams"},
+            "roofline": {"bound": "hbm", "kernel": "mrz_seq_narrow_kernel" if nnarrow * 2 > nseg else "mrz_sequencer_kernel",
+                         "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": pmc_traffic(nseg),
-                         "launches_per_step": nseg, "alg_bytes_per_step": alg_bytes,
+                         "traffic": pmc_traffic(), "traffic_source": "profiles (rocprofv3 --pmc passes, not this run)",
+                         "launches_per_step": nseg, "narrow_launches_per_step": nnarrow, "alg_bytes_per_step": alg_bytes,
                          "avg_launch_ms": round(seq_ms / steps / max(nseg, 1), 4)},
             "kernel_ms_per_step": {"sequencer": round(seq_ms / steps, 2), "tagscan": round(tag_ms / steps, 2),
                                    "encode": round(enc_ms / steps, 2), "crc32": round(crc_ms / steps, 2)},
@@ -190,12 +253,75 @@ def main():
         }
         if verify:
             out["verify"] = verify
+        if world == 1 and args.gib > 4.5:
+            # the S2 generator repeats itself exactly after 4 GiB (period i + 65536 equals period i): the tail of the
+            # chunk is ONE match.  Time the part that carries the matcher's work on its own.
+            n4 = 4 * GIB
+            ctx.victim_round = 0
+            ctx.rzip_chunk(data[:n4], fetch=False)
+            ctx.victim_round = 0
+            t4 = time.perf_counter()
+            r4, _, _ = ctx.rzip_chunk(data[:n4], fetch=False)
+            d4 = time.perf_counter() - t4
+            step_s = dt / steps
+            out["split"] = {"first_4GiB_GiBps": round(4.0 / d4, 4), "first_4GiB_matches": r4.stats.matches,
+                            "us_per_emitted_match_first_4GiB": round(d4 * 1e6 / max(r4.n_events, 1), 2),
+                            "tail_GiBps": round((n - n4) / GIB / max(step_s - d4, 1e-9), 2),
+                            "note": "beyond 4 GiB the stream repeats itself exactly: the tail is one match"}
+        if not args.no_shapes and world == 1:
+            del data
+            torch.cuda.empty_cache()
+            shapes = []
+            with m.RzipContext(level=args.level, max_chunk=256 << 20, device=dev_index, lib=lib) as c2:
+                c2.set_profiling(True)
+                shapes.append(shape_line(c2, "text-100M (S1, shape of configs[0])", workloads.zipf_text(100_000_000)))
+                shapes.append(shape_line(c2, "noise-64M", workloads.noise(64 << 20)))
+                shapes.append(shape_line(c2, "tar-like-128M (S3 mix, shape of configs[2])", workloads.tar_like(128 << 20)))
+            out["shapes"] = shapes
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(int(min(args.cpu_sample_gib, args.gib) * GIB))
+            out["cpu_baseline"] = cpu_baseline(ctx, int(min(args.cpu_sample_gib, args.gib) * GIB))
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def window_mode(args, m, workloads, lib, dist, rank, world, dev_index):
+    """ONE window over the ranks (BASELINE configs[3], scaled to --gib): S4 stride stream, range-sharded tag scan, tags
+    to rank 0 (send/recv over RCCL or gloo), exact matcher on rank 0."""
+    import torch
+    from modern_rzip_amd import shard
+    segp = 16 << 20
+    seg_bytes = max(int(args.gib * GIB) // 16 // segp, 1) * segp
+    win = workloads.stride_stream(16, seg_bytes, seed=99)  # the same bytes on every rank (seeded generator)
+    total = len(win)
+    ranges = shard.segment_ranges(total, world, segp)
+    off, size = ranges[rank]
+    mine = win[off:off + size + 48]
+    ctx = m.RzipContext(level=args.level, max_chunk=total if rank == 0 else 0, device=dev_index, lib=lib)
+    times = []
+    res = None
+    for it in range(args.warmup + args.steps):
+        dist.barrier()
+        t0 = time.perf_counter()
+        out = shard.rzip_chunk_window(ctx, mine, off, total, rank, world, dist, segp, gather_bytes=(it == 0))
+        dist.barrier()
+        if it >= args.warmup:
+            times.append(time.perf_counter() - t0)
+        if rank == 0:
+            res = out[0]
+    if rank == 0:
+        dt = sum(times)
+        print(json.dumps({"metric": "rzip-stage GiB/s (mrzip -n)", "value": round(total * args.steps / GIB / dt, 4),
+                          "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": f"stride-{total / GIB:g}G: ONE window (-U) of noise segments with planted "
+                                                 f"repeats (BASELINE configs[3], scaled), range-sharded over the GPUs",
+                                     "mode": "window", "level": args.level, "window_bytes": total},
+                          "result": {"s0_len": res.s0_len, "s1_len": res.s1_len, "matches": res.stats.matches}}), flush=True)
+    ctx.close()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -204,7 +204,10 @@ int mrz_lz4_sizes(mrz_ctx *ctx, const void *const *bufs, const int *lens, int co
 /* Streaming triple mirroring common/blake2b.h:47-49
  * (blake2b_init / blake2b_update / blake2b_final); the state lives on the
  * device and the kernel runs on a second low-priority stream of the ctx so it
- * overlaps the rzip kernels. */
+ * overlaps the rzip kernels.  Unlike blake2b_update, the call returns BEFORE the bytes have been read: host input is
+ * copied into a staging buffer first (reusable on return), DEVICE input must stay valid and unmodified until
+ * mrz_blake2b_final has returned.  Device input is ordered after everything already queued on the ctx stream
+ * (mrz_stream); producers on other streams have to be ordered by the caller. */
 typedef struct mrz_blake2b mrz_blake2b;
 int mrz_blake2b_init(mrz_ctx *ctx, mrz_blake2b **st, size_t outlen);
 int mrz_blake2b_update(mrz_blake2b *st, const void *in, size_t inlen, int where);

@@ -233,6 +233,19 @@ extern "C" int mrz_blake2b_update(mrz_blake2b *s, const void *in, size_t inlen, 
         d = s->d_in;
     } else if (where != MRZ_MEM_DEVICE)
         return MRZ_E_ARG;
+    else {
+        // device input: whatever the ctx stream has queued so far (e.g. the kernels that produce d_s0 / d_s1 of a
+        // chunk) comes first; work queued on other streams is the caller's to order (mrzgpu.h)
+        hipEvent_t ev = nullptr;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side_stream, ev, 0);
+        hipEventDestroy(ev);
+        if (e != hipSuccess) {
+            ctx->last_err = e;
+            return MRZ_E_HIP;
+        }
+    }
     hipLaunchKernelGGL(mrz_blake2b_update_kernel, dim3(1), dim3(64), 0, ctx->side_stream, s->d_state, d,
                        (uint64_t)inlen);
     HIPCHK(ctx, hipGetLastError());

@@ -332,6 +332,7 @@ struct mrzo_matcher {
     int64_t min_mask, clean_ptr, last_match;
     int64_t victim_round;
     mrzo_stats st;
+    int bytewise; /* compare one byte at a time, as single_match_len does (src/rzip.c:378), not eight */
 };
 
 /* levels[], src/rzip.c:65-73 */
@@ -370,6 +371,7 @@ void mrzo_matcher_free(mrzo_matcher *m) {
 
 int64_t mrzo_matcher_get_victim_round(const mrzo_matcher *m) { return m->victim_round; }
 void mrzo_matcher_set_victim_round(mrzo_matcher *m, int64_t v) { m->victim_round = v; }
+void mrzo_matcher_set_bytewise(mrzo_matcher *m, int on) { m->bytewise = on ? 1 : 0; }
 const mrzo_stats *mrzo_matcher_stats(const mrzo_matcher *m) { return &m->st; }
 int64_t mrzo_matcher_min_mask(const mrzo_matcher *m) { return m->min_mask; }
 int64_t mrzo_matcher_hash_count(const mrzo_matcher *m) { return m->count; }
@@ -465,10 +467,11 @@ static int64_t table_cull_one(mrzo_matcher *m) {
 }
 
 /* single_match_len, src/rzip.c:372-397 */
-static int64_t extend_match(const uint8_t *buf, int64_t p0, int64_t op, int64_t end, int64_t last_match, int64_t *rev) {
+static int64_t extend_match(const uint8_t *buf, int64_t p0, int64_t op, int64_t end, int64_t last_match, int64_t *rev,
+                            int bytewise) {
     if (op >= p0) return 0;
     int64_t p = p0, q = op;
-    while (p + 8 <= end) {
+    while (!bytewise && p + 8 <= end) {
         uint64_t a, b;
         memcpy(&a, buf + p, 8);
         memcpy(&b, buf + q, 8);
@@ -509,7 +512,7 @@ static int64_t table_lookup(mrzo_matcher *m, const uint8_t *buf, int64_t t, int6
     while (!slot_empty(s)) {
         if (s->t == t) {
             int64_t rev = 0;
-            int64_t ml = extend_match(buf, p, s->offset, end, m->last_match, &rev);
+            int64_t ml = extend_match(buf, p, s->offset, end, m->last_match, &rev, m->bytewise);
             if (ml) {
                 if (ml > best) {
                     best = ml;

@@ -95,6 +95,9 @@ mrzo_matcher *mrzo_matcher_new(int level);
 void mrzo_matcher_free(mrzo_matcher *m);
 int64_t mrzo_matcher_get_victim_round(const mrzo_matcher *m);
 void mrzo_matcher_set_victim_round(mrzo_matcher *m, int64_t v);
+/* timing variant: extend matches one byte at a time like single_match_len (src/rzip.c:378) instead of eight -- the
+ * same results, the reference's inner loop shape (bench.py reports both as cpu_baseline) */
+void mrzo_matcher_set_bytewise(mrzo_matcher *m, int on);
 const mrzo_stats *mrzo_matcher_stats(const mrzo_matcher *m);
 /* table introspection (show_distrib, src/rzip.c:464-485) */
 void mrzo_matcher_distrib(const mrzo_matcher *m, int64_t *total, int64_t *primary);

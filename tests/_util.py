@@ -80,13 +80,16 @@ class Oracle:
         self.L.mrzo_hash_index(H)
         return list(H)
 
-    def rzip_chunk(self, data, level=7, victim_round=0, want_table=False):
-        """-> dict(s0, s1, crc, stats, victim_round, min_mask, hash_count[, table])"""
+    def rzip_chunk(self, data, level=7, victim_round=0, want_table=False, bytewise=False):
+        """-> dict(s0, s1, crc, stats, victim_round, min_mask, hash_count[, table]); bytewise: the reference's
+        byte-at-a-time match extension (same results, timing variant)"""
         L = self.L
         m = ctypes.c_void_p(L.mrzo_matcher_new(level))
         assert m
         try:
             L.mrzo_matcher_set_victim_round(m, victim_round)
+            if bytewise:
+                L.mrzo_matcher_set_bytewise(m, 1)
             s0, s1, crc = Buf(), Buf(), ctypes.c_uint32()
             cb = L.mrzo_chunk_bytes(len(data))
             rc = L.mrzo_rzip_chunk(m, data, len(data), cb, ctypes.byref(s0), ctypes.byref(s1), ctypes.byref(crc))

@@ -55,3 +55,19 @@ def test_host_control_layout_matches_header():
         "rzip_compression_level", "compression_level", "window", "unlimited", "ramsize", "page_size", "hash_code",
         "device", "lz4_test", "threshold"]
     assert ctypes.sizeof(m.ChunkResult) == 8 + 8 + 4 + 4 + 8 + 8 + 56 + 24
+
+
+def test_integration_snippet_compiles_and_matches_the_document():
+    """INTEGRATION.md section 1 is real code: the copy in tests/c/integration_snippet.c passes gcc -fsyntax-only against
+    include/mrzgpu.h and the reference prototypes it names, and the document holds the same text."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "c", "integration_snippet.c")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "tests", "c"), src], check=True)
+    text = open(src).read()
+    body = text[text.index("*/\n", text.index("BEGIN SNIPPET")) + 3:text.index("/* END SNIPPET */")]
+    assert body in open(os.path.join(root, "INTEGRATION.md")).read()
+    # the C caller test is valid C99 against the public headers as well (it runs in the GPU tier)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "oracle"), os.path.join(root, "tests", "c", "capi_test.c")], check=True)

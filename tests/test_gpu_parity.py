@@ -442,3 +442,18 @@ def test_rzip_fd_on_a_pipe_and_on_a_file(gpu_lib, oracle, tmp_path):
     data = _util.rep64k(40, seed=3) + _util.zipf_text(3 << 20, seed=5)
     _parity.check_fd(gpu_lib, oracle, data, use_pipe=True, ramsize=3 << 20, tmp_path=tmp_path)
     _parity.check_fd(gpu_lib, oracle, data, use_pipe=False, ramsize=3 << 20, tmp_path=tmp_path)
+
+
+def test_c_caller_program(gpu_lib, tmp_path):
+    """tests/c/capi_test.c: a plain C99 program (gcc, no ctypes) linked against libmrzgpu.so drives the chunk call and
+    mrz_rzip_fd (file and pipe) and compares every byte with the oracle itself."""
+    import subprocess
+    exe = str(tmp_path / "capi_test")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"),
+                    os.path.join(ROOT, "tests", "c", "capi_test.c"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "modern-rzip_amd"), "-lmrzgpu", "-L" + os.path.join(ROOT, "oracle"), "-loracle"],
+                   check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([os.path.join(ROOT, "modern-rzip_amd"), os.path.join(ROOT, "oracle"),
+                                                            os.environ.get("LD_LIBRARY_PATH", "")]))
+    out = subprocess.run([exe], check=True, env=env, stdout=subprocess.PIPE, text=True).stdout
+    assert "capi_test ok" in out
