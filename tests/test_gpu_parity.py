@@ -457,3 +457,16 @@ def test_c_caller_program(gpu_lib, tmp_path):
                                                             os.environ.get("LD_LIBRARY_PATH", "")]))
     out = subprocess.run([exe], check=True, env=env, stdout=subprocess.PIPE, text=True).stdout
     assert "capi_test ok" in out
+
+
+def test_coresident_blake2b_and_rs_beside_rzip(gpu_lib):
+    """BASELINE configs[4] (scaled): the BLAKE2b kernels and the rs-mrzip encoder run from other host threads, on
+    their own ctxs / streams, WHILE a chunk is being sequenced -- every output identical to its solo run."""
+    sys_path_tools = os.path.join(ROOT, "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("probe_coresident", os.path.join(sys_path_tools, "probe_coresident.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    line = mod.main(rz_mib=128, b2_msgs=512, b2_kib=256, rs_mib=64)
+    assert line["outputs_identical"]
+    assert line["together_wall_s"] < line["sum_of_solo_s"] * 1.05  # they overlap instead of queueing behind each other
