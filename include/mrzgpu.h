@@ -229,6 +229,22 @@ int mrz_blake2b_batch(mrz_ctx *ctx, const void *const *msgs, const int64_t *lens
 int64_t mrz_rs_encoded_size(int64_t n);
 int mrz_rs_encode(mrz_ctx *ctx, const void *in, int64_t n, int where, void *out, int out_where, int64_t out_cap);
 
+/* Replaces decode() of rs-mrzip (rs-mrzip/rs-mrzip.c:37-117): de-interleave every burst (gather,
+ * rs-mrzip/reed-solomon.c:323-333), correct every 255-byte codeword (rsd32, :143-309: syndromes, Berlekamp-Massey,
+ * Chien search, Forney; up to 16 byte errors per codeword), check the BLAKE2b-512 of the decoded rows against the
+ * trailer and strip the zero padding ({k_i, k_j}).  `in`: what `rs-mrzip` (or mrz_rs_encode) wrote, possibly damaged;
+ * out_host: room for mrz_rs_encoded_size's input, i.e. (n / 2084880) * 1823248 bytes; *out_len: the bytes `rs-mrzip -d`
+ * writes to stdout.  rep: what it prints -- corrected byte errors, uncorrectable codewords (left as they are, like
+ * the reference), whether the checksum matched, whether the trailer was missing (then nothing is stripped). */
+typedef struct {
+    int64_t corrected;
+    int64_t uncorrectable;
+    int32_t checksum_ok;
+    int32_t truncated;
+} mrz_rs_report;
+int mrz_rs_decode(mrz_ctx *ctx, const void *in, int64_t n, int where, void *out_host, int64_t out_cap, int64_t *out_len,
+                  mrz_rs_report *rep);
+
 /* ---- runzip: decoder of the two rzip streams of a chunk ---------- */
 
 /* Replaces the record loop of runzip_chunk (src/runzip.c:277-308) with unzip_literal (:120-157) and

@@ -39,6 +39,11 @@ TAG_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.
                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 
 
+class RsReport(ctypes.Structure):
+    _fields_ = [("corrected", ctypes.c_int64), ("uncorrectable", ctypes.c_int64), ("checksum_ok", ctypes.c_int32),
+                ("truncated", ctypes.c_int32)]
+
+
 class Control(ctypes.Structure):
     """The rzip_control fields rzip_fd reads for `mrzip -n` (include/mrzgpu_host.h)."""
     _fields_ = [("rzip_compression_level", ctypes.c_int), ("compression_level", ctypes.c_int),
@@ -89,6 +94,8 @@ def load_library(path=None):
     lib.mrz_strerror.argtypes = [ci]
     lib.mrz_strerror.restype = ctypes.c_char_p
     lib.mrz_last_hip_error.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p)]
+    if hasattr(lib, "mrz_rs_decode"):
+        lib.mrz_rs_decode.argtypes = [vp, vp, i64, ci, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(RsReport)]
     if hasattr(lib, "mrz_window_scan"):
         lib.mrz_window_scan.argtypes = [vp, vp, i64, ci, i64, i64, i64, i64, i64, i64, vp, vp]
         lib.mrz_set_tag_provider.argtypes = [vp, TAG_FN, vp]
@@ -312,6 +319,18 @@ class RzipContext:
         out = ctypes.create_string_buffer(total)
         _check(self.lib, self.lib.mrz_rs_encode(self.ctx, ptr, n, where, out, MEM_HOST, total), self.ctx)
         return out.raw
+
+    def rs_decode(self, data):
+        """mrz_rs_decode -> (bytes, dict(corrected, uncorrectable, checksum_ok, truncated))."""
+        ptr, n, where, keep = _as_ptr(data)
+        cap = (n // 2084880) * 1823248
+        out = ctypes.create_string_buffer(max(cap, 1))
+        out_len = ctypes.c_int64()
+        rep = RsReport()
+        _check(self.lib, self.lib.mrz_rs_decode(self.ctx, ptr, n, where, out, cap, ctypes.byref(out_len), ctypes.byref(rep)),
+               self.ctx)
+        return out.raw[:out_len.value], dict(corrected=rep.corrected, uncorrectable=rep.uncorrectable,
+                                             checksum_ok=bool(rep.checksum_ok), truncated=bool(rep.truncated))
 
     # ---- runzip (src/runzip.c:120-207,277-308) ----
     def runzip_chunk(self, s0, s1, chunk_bytes_, out_cap, out=None):

@@ -36,6 +36,8 @@ struct mrz_rs_tables {
     uint8_t fbgen[256][32];  // fbgen[f][j] = f * g_j in GF(256), conventional basis
     uint8_t tal[256];        // conventional -> dual basis
     uint8_t tal1[256];       // dual -> conventional
+    uint8_t ex[256];         // alpha^i (index -> polynomial form), ex[255] = 0     (Alpha_to, reed-solomon.c:28)
+    uint8_t lg[256];         // log_alpha (polynomial -> index form), lg[0] = 255   (Index_of, :43)
 };
 
 static void mrz_rs_build_tables(mrz_rs_tables *T) {
@@ -65,6 +67,12 @@ static void mrz_rs_build_tables(mrz_rs_tables *T) {
         T->tal[i] = t;
     }
     for (int i = 0; i < 256; i++) T->tal1[T->tal[i]] = (uint8_t)i;
+    for (int i = 0; i < 255; i++) {
+        T->ex[i] = ex[i];
+        T->lg[ex[i]] = (uint8_t)i;
+    }
+    T->ex[255] = 0;
+    T->lg[0] = 255;
 }
 
 // grid.x = bursts * 73; each workgroup: 112 rows of one burst
@@ -332,5 +340,225 @@ extern "C" int mrz_rs_encode(mrz_ctx *ctx, const void *in, int64_t n, int where,
         memcpy((uint8_t *)out + nbursts * burst_out, tail, 68);
     else
         HIPCHK(ctx, hipMemcpy((uint8_t *)out + nbursts * burst_out, tail, 68, hipMemcpyHostToDevice));
+    return MRZ_OK;
+}
+
+
+// ---- rs-mrzip decoder (rs-mrzip/rs-mrzip.c:37-117 decode(), reed-solomon.c:143-309 rsd32, :323-333 gather) ------
+// One lane per codeword: the 8176 rows of a burst are independent.  A workgroup takes 128 rows: the interleaved
+// input is read column by column (byte c of row r at c * 8176 + r: coalesced across the lanes), converted to the
+// conventional basis (tal1tab) into an LDS image, and the 32 syndromes are accumulated on the way.  Rows whose
+// syndromes vanish -- all of them on undamaged input -- are done; the others run Berlekamp-Massey, the Chien search
+// and Forney's formula exactly as rsd32 does (same field, same roots alpha^(11 (112 + i)), same order of operations,
+// so that miscorrections and "uncorrectable" verdicts agree too), each lane on its own row.  The image goes back
+// through taltab and out as 223 data bytes per row, row-major.
+#define MRZ_RSD_ROWS 128
+#define MRZ_RSD_STRIDE 260  // bytes per LDS row (65 words: lanes of a wave hit different banks)
+
+__device__ static int mrz_rsd_slow(uint8_t *data, const int *s_in, const uint8_t *ex, const uint8_t *lg) {
+    // s_in[1..32]: syndromes in index form (255 = zero).  no_eras = 0 (rs-mrzip never passes erasures).
+    int lambda[33], b[33], t[33], omega[33], reg[33], root[32], loc[32], s[33];
+    for (int i = 1; i <= 32; i++) s[i] = s_in[i];
+    for (int i = 0; i < 33; i++) lambda[i] = 0;
+    lambda[0] = 1;
+    for (int i = 0; i < 33; i++) b[i] = lg[lambda[i]];
+    int r = 0, el = 0;
+    while (++r <= 32) {  // Berlekamp-Massey, :203-232
+        int discr = 0;
+        for (int i = 0; i < r; i++)
+            if (lambda[i] != 0 && s[r - i] != 255) discr ^= ex[(lg[lambda[i]] + s[r - i]) % 255];
+        discr = lg[discr];
+        if (discr == 255) {
+            for (int i = 32; i > 0; i--) b[i] = b[i - 1];
+            b[0] = 255;
+        } else {
+            t[0] = lambda[0];
+            for (int i = 0; i < 32; i++) t[i + 1] = b[i] != 255 ? (lambda[i + 1] ^ ex[(discr + b[i]) % 255]) : lambda[i + 1];
+            if (2 * el <= r - 1) {
+                el = r - el;
+                for (int i = 0; i <= 32; i++) b[i] = lambda[i] == 0 ? 255 : (lg[lambda[i]] - discr + 255) % 255;
+            } else {
+                for (int i = 32; i > 0; i--) b[i] = b[i - 1];
+                b[0] = 255;
+            }
+            for (int i = 0; i < 33; i++) lambda[i] = t[i];
+        }
+    }
+    int deg_lambda = 0;
+    for (int i = 0; i < 33; i++) {
+        lambda[i] = lg[lambda[i]];
+        if (lambda[i] != 255) deg_lambda = i;
+    }
+    for (int i = 1; i <= 32; i++) reg[i] = lambda[i];
+    int count = 0;
+    for (int i = 1, k = 139; i <= 255; i++, k = (k + 139) % 255) {  // Chien search, :244-258
+        int q = 1;
+        for (int j = deg_lambda; j > 0; j--)
+            if (reg[j] != 255) {
+                reg[j] = (reg[j] + j) % 255;
+                q ^= ex[reg[j]];
+            }
+        if (q != 0) continue;
+        root[count] = i;
+        loc[count] = k;
+        if (++count == deg_lambda) break;
+    }
+    if (deg_lambda != count) return -1;  // uncorrectable, :259-264
+    int deg_omega = 0;
+    for (int i = 0; i < 32; i++) {  // omega(x) = s(x) lambda(x) mod x^32, :267-276
+        int tmp = 0;
+        for (int j = deg_lambda < i ? deg_lambda : i; j >= 0; j--)
+            if (s[i + 1 - j] != 255 && lambda[j] != 255) tmp ^= ex[(s[i + 1 - j] + lambda[j]) % 255];
+        if (tmp != 0) deg_omega = i;
+        omega[i] = lg[tmp];
+    }
+    omega[32] = 255;
+    for (int j = count - 1; j >= 0; j--) {  // Forney, :280-301
+        int num1 = 0;
+        for (int i = deg_omega; i >= 0; i--)
+            if (omega[i] != 255) num1 ^= ex[(omega[i] + i * root[j]) % 255];
+        const int num2 = ex[(root[j] * 111) % 255];
+        int den = 0;
+        for (int i = (deg_lambda < 31 ? deg_lambda : 31) & ~1; i >= 0; i -= 2)
+            if (lambda[i + 1] != 255) den ^= ex[(lambda[i + 1] + i * root[j]) % 255];
+        if (den == 0) return -1;  // (what has been applied so far stays applied, as in the reference)
+        if (num1 != 0) data[loc[j]] ^= ex[(lg[num1] + lg[num2] + 255 - lg[den]) % 255];
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(MRZ_RSD_ROWS) void mrz_rs_decode_kernel(const uint8_t *__restrict__ in, int64_t nbursts,
+                                                                     const mrz_rs_tables *__restrict__ T,
+                                                                     uint8_t *__restrict__ out, int *__restrict__ counts) {
+    __shared__ uint8_t s_ex[256], s_lg[256], s_tal[256], s_tal1[256];
+    __shared__ __attribute__((aligned(4))) uint8_t s_img[MRZ_RSD_ROWS * MRZ_RSD_STRIDE];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 256; i += MRZ_RSD_ROWS) {
+        s_ex[i] = T->ex[i];
+        s_lg[i] = T->lg[i];
+        s_tal[i] = T->tal[i];
+        s_tal1[i] = T->tal1[i];
+    }
+    __syncthreads();
+    const int tiles = (MRZ_RS_ROWS + MRZ_RSD_ROWS - 1) / MRZ_RSD_ROWS;  // 64: the last one holds 112 rows
+    const int64_t burst = blockIdx.x / tiles;
+    const int row0 = (int)(blockIdx.x % tiles) * MRZ_RSD_ROWS;
+    const int nrows = MRZ_RS_ROWS - row0 < MRZ_RSD_ROWS ? MRZ_RS_ROWS - row0 : MRZ_RSD_ROWS;
+    const uint8_t *src = in + burst * (int64_t)MRZ_RS_N * MRZ_RS_ROWS + row0;
+    uint8_t *row = &s_img[tid * MRZ_RSD_STRIDE];
+    int count = 0;
+    if (tid < nrows) {
+        // gather + dual -> conventional + syndromes: s[i] = sum_j data[j] alpha^((111 + i) 11 j), :156-166
+        int s[33], pw[33];
+#pragma unroll
+        for (int i = 1; i <= 32; i++) {
+            s[i] = 0;
+            pw[i] = 0;
+        }
+        for (int c = 0; c < MRZ_RS_N; c++) {
+            const int d = s_tal1[src[(int64_t)c * MRZ_RS_ROWS + tid]];
+            row[c] = (uint8_t)d;
+            if (d != 0) {
+                const int lgd = s_lg[d];
+#pragma unroll
+                for (int i = 1; i <= 32; i++) {
+                    int e = lgd + pw[i];
+                    e = e >= 255 ? e - 255 : e;
+                    s[i] ^= s_ex[e];
+                }
+            }
+#pragma unroll
+            for (int i = 1; i <= 32; i++) {  // exponent of column c + 1
+                int e = pw[i] + ((111 + i) * 11) % 255;
+                pw[i] = e >= 255 ? e - 255 : e;
+            }
+        }
+        int syn_error = 0;
+#pragma unroll
+        for (int i = 1; i <= 32; i++) {
+            syn_error |= s[i];
+            s[i] = s_lg[s[i]];
+        }
+        if (syn_error) count = mrz_rsd_slow(row, s, s_ex, s_lg);
+        counts[burst * MRZ_RS_ROWS + row0 + tid] = count;
+    }
+    __syncthreads();
+    // the data bytes of the rows, back in the dual basis (taltab, :305), row-major
+    uint8_t *dst = out + (burst * MRZ_RS_ROWS + row0) * (int64_t)MRZ_RS_K;
+    for (int idx = tid; idx < nrows * MRZ_RS_K; idx += MRZ_RSD_ROWS) {
+        const int r = idx / MRZ_RS_K, c = idx % MRZ_RS_K;
+        dst[idx] = s_tal[s_img[r * MRZ_RSD_STRIDE + c]];
+    }
+    (void)nbursts;
+}
+
+extern "C" int mrz_rs_decode(mrz_ctx *ctx, const void *in, int64_t n, int where, void *out_host, int64_t out_cap,
+                             int64_t *out_len, mrz_rs_report *rep) {
+    if (!ctx || !in || !out_host || !out_len || n < 0) return MRZ_E_ARG;
+    const int64_t burst_in = (int64_t)MRZ_RS_K * MRZ_RS_ROWS, burst_out = (int64_t)MRZ_RS_N * MRZ_RS_ROWS;
+    const int64_t nbursts = n / burst_out;
+    const int64_t tail = n - nbursts * burst_out;
+    if (nbursts < 1) return MRZ_E_CORRUPT;
+    if (out_cap < nbursts * burst_in) return MRZ_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint8_t *d_in = nullptr;
+    int rc = mrz_stage_input(ctx, in, n, where, &d_in);
+    if (rc) return rc;
+    if (!ctx->d_rs_tables) {
+        mrz_rs_tables *T = (mrz_rs_tables *)malloc(sizeof(mrz_rs_tables));
+        void *p = nullptr;
+        hipError_t e = T ? hipMalloc(&p, sizeof(mrz_rs_tables)) : hipErrorOutOfMemory;
+        if (e == hipSuccess) {
+            mrz_rs_build_tables(T);
+            e = hipMemcpy(p, T, sizeof(mrz_rs_tables), hipMemcpyHostToDevice);
+        }
+        free(T);
+        if (e != hipSuccess) {
+            ctx->last_err = e;
+            return MRZ_E_NOMEM;
+        }
+        ctx->d_rs_tables = p;
+    }
+    // device output: rows x 223 bytes, then one count per row
+    const int64_t rows = nbursts * MRZ_RS_ROWS;
+    rc = mrz_grow(ctx, &ctx->d_rs_out, &ctx->rs_out_cap, rows * MRZ_RS_K + rows * 4 + 16);
+    if (rc) return rc;
+    uint8_t *d_out = ctx->d_rs_out;
+    int *d_counts = (int *)(d_out + ((rows * MRZ_RS_K + 15) / 16) * 16);
+    const int tiles = (MRZ_RS_ROWS + MRZ_RSD_ROWS - 1) / MRZ_RSD_ROWS;
+    hipLaunchKernelGGL(mrz_rs_decode_kernel, dim3((unsigned)(nbursts * tiles)), dim3(MRZ_RSD_ROWS), 0, ctx->stream, d_in,
+                       nbursts, (const mrz_rs_tables *)ctx->d_rs_tables, d_out, d_counts);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<int> counts((size_t)rows);
+    HIPCHK(ctx, hipMemcpyAsync(out_host, d_out, (size_t)(rows * MRZ_RS_K), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(counts.data(), d_counts, (size_t)rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    mrz_rs_report r;
+    memset(&r, 0, sizeof(r));
+    for (int64_t i = 0; i < rows; i++) {  // rs-mrzip.c:103-108
+        if (counts[(size_t)i] > 0) r.corrected += counts[(size_t)i];
+        if (counts[(size_t)i] == -1) r.uncorrectable++;
+    }
+    int64_t produced = rows * MRZ_RS_K;
+    if (tail == 64 + 4) {
+        // trailer: BLAKE2b-512 of every 223-byte row as decoded, then the first short row and its length (:70-95)
+        uint8_t trailer[68], digest[64];
+        if (where == MRZ_MEM_HOST)
+            memcpy(trailer, (const uint8_t *)in + nbursts * burst_out, 68);
+        else
+            HIPCHK(ctx, hipMemcpy(trailer, (const uint8_t *)in + nbursts * burst_out, 68, hipMemcpyDeviceToHost));
+        HostB2 b;
+        b.update((const uint8_t *)out_host, (size_t)produced);
+        b.final(digest);
+        r.checksum_ok = memcmp(digest, trailer, 64) == 0;
+        const int64_t k_i = trailer[64] | trailer[65] << 8, k_j = trailer[66] | trailer[67] << 8;
+        if (k_i < MRZ_RS_ROWS) {
+            const int64_t cut = (nbursts - 1) * burst_in + k_i * MRZ_RS_K + (k_j < MRZ_RS_K ? k_j : MRZ_RS_K);
+            if (cut < produced) produced = cut;
+        }
+    } else
+        r.truncated = 1;  // "file truncated. can't validate the checksum or remove superfluous 0x00 padding" (:58-68)
+    *out_len = produced;
+    if (rep) *rep = r;
     return MRZ_OK;
 }

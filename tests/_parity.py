@@ -104,6 +104,57 @@ def check_fd(lib, oracle, data, use_pipe, ramsize, tmp_path, level=7):
     return got
 
 
+def ref_rs_decode(enc):
+    """`rs-mrzip -d` on `enc` with the REFERENCE's own rsd32 / gather (oracle/_ref/librs_ref.so = rs-mrzip/reed-solomon.c
+    compiled in place) and decode()'s loop (rs-mrzip/rs-mrzip.c:37-117) around them: (bytes, report)."""
+    import ctypes
+    import os
+    ref = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                                   "librs_ref.so"))
+    ROWS, BURST = 8176, 8176 * 255
+    nb = len(enc) // BURST
+    tail = enc[nb * BURST:]
+    rows_out = bytearray()
+    corrected = uncorrectable = 0
+    for b in range(nb):
+        tr = ctypes.create_string_buffer(enc[b * BURST:(b + 1) * BURST], BURST)
+        ec = ctypes.create_string_buffer(BURST)
+        ref.gather(tr, ec, ROWS, 255)
+        eras = (ctypes.c_int * 32)()
+        base = ctypes.addressof(ec)
+        for i in range(ROWS):
+            f = ref.rsd32(ctypes.c_void_p(base + i * 255), eras, 0)
+            if f > 0:
+                corrected += f
+            elif f == -1:
+                uncorrectable += 1
+        raw = ec.raw
+        for i in range(ROWS):
+            rows_out += raw[i * 255:i * 255 + 223]
+    rep = dict(corrected=corrected, uncorrectable=uncorrectable, checksum_ok=False, truncated=len(tail) != 68)
+    out = bytes(rows_out)
+    if len(tail) == 68:
+        rep["checksum_ok"] = hashlib.blake2b(out).digest() == tail[:64]
+        k_i, k_j = tail[64] | tail[65] << 8, tail[66] | tail[67] << 8
+        if k_i < ROWS:
+            out = out[:(nb - 1) * ROWS * 223 + k_i * 223 + k_j]
+    return out, rep
+
+
+def check_rs_decode(ctx, data, damage):
+    """encode (GPU) -> damage -> decode (GPU) == the reference's decoder on the same damaged bytes."""
+    enc = bytearray(ctx.rs_encode(data))
+    for at, n, val in damage:
+        for k in range(n):
+            enc[at + k] ^= val
+    enc = bytes(enc)
+    got, rep = ctx.rs_decode(enc)
+    want, wrep = ref_rs_decode(enc)
+    assert rep == wrep, (rep, wrep)
+    assert got == want
+    return got, rep
+
+
 def _blocks_of_archive(mrz):
     """(stream, payload) of every block of a -n archive in FILE order = the reference's flush order
     (src/stream.c:1199-1293): walks the chunks, finds every block header by following both chains."""

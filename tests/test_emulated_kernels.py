@@ -125,6 +125,28 @@ def test_rs_encoder(emu_lib, oracle):
             assert ctx.rs_encode(d) == oracle.rs_encode(d), n
 
 
+def test_rs_decoder_against_the_reference(emu_lib):
+    """rsd32 / gather / decode() (rs-mrzip/reed-solomon.c:143-333, rs-mrzip.c:37-117): undamaged input, bursts of errors
+    that the interleave spreads over many codewords, a codeword with exactly 16 and with more than 16 errors."""
+    data = _util.xorshift_noise(300000, seed=5)
+    with m.RzipContext(lib=emu_lib) as ctx:
+        got, rep = _parity.check_rs_decode(ctx, data, [])
+        assert got == data and rep == dict(corrected=0, uncorrectable=0, checksum_ok=True, truncated=False)
+        # a burst of 4 * 8176 damaged bytes = 4 errors in every codeword; 16 errors in row 7; 17 in row 9
+        dmg = [(1000, 4 * 8176, 0x5a)] + [((20 + 3 * k) * 8176 + 7, 1, 0x11) for k in range(16)]
+        dmg += [((100 + 2 * k) * 8176 + 9, 1, 0x80) for k in range(17)]
+        got, rep = _parity.check_rs_decode(ctx, data, dmg)
+        assert rep["uncorrectable"] >= 1 and rep["corrected"] >= 4 * 8170 and not rep["checksum_ok"]
+        got, rep = _parity.check_rs_decode(ctx, data, dmg[1:17])  # 16 errors in one codeword: the limit
+        assert got == data and rep["checksum_ok"] and rep == dict(corrected=16, uncorrectable=0, checksum_ok=True,
+                                                                   truncated=False)
+        # trailer damaged / missing
+        _parity.check_rs_decode(ctx, data, [(2084880 + 3, 1, 1)])
+        enc = ctx.rs_encode(data)
+        got, rep = ctx.rs_decode(enc[:-68])
+        assert rep["truncated"] and got[:len(data)] == data and len(got) == 8176 * 223
+
+
 def test_runzip_overlapping_and_corrupt_streams(emu_lib, oracle):
     # hand-made streams: literal "abc", match len 10 dist 3 (the 3 history bytes repeat, src/runzip.c:182-199),
     # match len 4 dist 13 (plain copy), terminator + CRC

@@ -470,3 +470,17 @@ def test_coresident_blake2b_and_rs_beside_rzip(gpu_lib):
     line = mod.main(rz_mib=128, b2_msgs=512, b2_kib=256, rs_mib=64)
     assert line["outputs_identical"]
     assert line["together_wall_s"] < line["sum_of_solo_s"] * 1.05  # they overlap instead of queueing behind each other
+
+
+def test_rs_decoder_against_the_reference(gpu_lib):
+    """mrz_rs_decode vs the reference's own rsd32 / gather (oracle/_ref/librs_ref.so) on damaged encodings."""
+    data = _util.xorshift_noise(2 * 1823248 + 777, seed=15)  # three bursts
+    with m.RzipContext(lib=gpu_lib) as ctx:
+        got, rep = _parity.check_rs_decode(ctx, data, [])
+        assert got == data and rep == dict(corrected=0, uncorrectable=0, checksum_ok=True, truncated=False)
+        dmg = [(5000, 16 * 8176, 0xa5), (2084880 + 999, 3 * 8176 + 100, 0x3c)]  # 16 errors per codeword: the limit
+        got, rep = _parity.check_rs_decode(ctx, data, dmg)
+        assert got == data and rep["checksum_ok"] and rep["corrected"] == 16 * 8176 + 3 * 8176 + 100
+        dmg.append((2 * 2084880, 17 * 8176, 0x77))  # 17 per codeword in the last burst: beyond repair
+        got, rep = _parity.check_rs_decode(ctx, data, dmg)
+        assert rep["uncorrectable"] > 0 and not rep["checksum_ok"]
