@@ -756,6 +756,8 @@ struct mrz_cfg {
     int n_helpers;             // helper workgroups in this launch
     int64_t *farm_hint;        // forward length of the last long match: go to the farm at once when it was big
     int *long_seen;            // set when a look-up had entries beyond the 64-byte reach (scheduling hint only)
+    int *sc_seq;               // scout hand-off counter (shared with the main loop)
+    int64_t *pred_end;         // where the match being measured is expected to end (last end + last stride), or -1
 };
 
 // lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
@@ -980,6 +982,18 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_ba
         mrz_farm_census(C);
         if (*C.gnw >= 2 * MRZ_FARM_ENTRIES && (nlong >= 2 || *C.farm_hint >= MRZ_FARM_HINT_MIN)) {
             int64_t fw, rv;
+#ifdef MRZ_PRED_SCOUT  // measured: -2.8 % on the benchmark stream (the extra loads compete with the farm), off
+            // While the helpers compare, the scout warms the caches for what comes AFTER this match: on a stream that
+            // is one long match after another the ends are evenly spaced, so the next position is predictable (pure
+            // prefetch: a wrong guess costs nothing but the loads).
+            if (MRZ_HAVE_SCOUT && *C.pred_end > qx) {
+                *C.sc_seq += 1;
+                if (lane == 0) {
+                    mb->scout_pos = *C.pred_end;
+                    mrz_mb_store(&mb->scout_seq, *C.sc_seq);
+                }
+            }
+#endif
             if (mrz_farm(C, B, qx, C.end - qx, floor_p, 0, nsx, my_op, my_r < 0 && my_op < qx, true, lane, stat, &fw,
                          &rv)) {
                 if (my_r < 0) {
@@ -1911,6 +1925,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_seq_narrow_kernel(mrz_seq
 
     int sc_seq = 0;
     int64_t sc_last = -1;
+    C.sc_seq = &sc_seq;
+    int64_t pred_end = -1, prev_end = -1;
+    C.pred_end = &pred_end;
     while (ok) {
         PROF_T0();
         if (MRZ_HAVE_SCOUT && L.p != sc_last) {
@@ -1999,6 +2016,11 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_seq_narrow_kernel(mrz_seq
             c = first_was_long ? (c < 3 ? c + 1 : 3) : (c > 0 ? c - 1 : 0);
         }
         after_emit = L.n_events != ev_before;
+        if (after_emit) {  // stride predictor of match ends
+            const int64_t stride = prev_end >= 0 ? L.last_match - prev_end : 0;
+            prev_end = L.last_match;
+            pred_end = (stride > 0 && stride < (1ll << 28)) ? L.last_match + stride : -1;
+        }
         if (after_emit) emit_cls = ((emit_cls << 1) & 2) | (L.last_len >= MRZ_GREAT_MATCH ? 1 : 0);
     }
 

@@ -68,6 +68,35 @@ def tar_like(nbytes, seed=5):
     return bytes(out[:nbytes])
 
 
+def tar_like_fast(nbytes, seed=5, pool_bytes=48 << 20):
+    """The S3 mix at sizes of a GiB and more without generating a GiB of Zipf text word by word: text members are
+    slices of one text pool at random offsets (so parts of members repeat each other at distances of up to the whole
+    stream), noise members come straight from the generator, 15 % are exact duplicates of earlier members;
+    512-byte aligned like tar_like."""
+    rng = np.random.default_rng(seed)
+    pool = np.frombuffer(zipf_text(pool_bytes, seed=seed + 1), dtype=np.uint8)
+    out = np.empty(nbytes + (8 << 20), dtype=np.uint8)
+    at, members = 0, []
+    while at < nbytes:
+        kind = rng.random()
+        size = int(2 ** rng.uniform(10, 22))
+        if kind < 0.6 or not members:
+            off = int(rng.integers(0, len(pool) - size))
+            out[at:at + size] = pool[off:off + size]
+        elif kind < 0.85:
+            out[at:at + size] = rng.integers(0, 256, size=size, dtype=np.uint8)
+        else:
+            m0, msz = members[int(rng.integers(0, len(members)))]
+            size = msz
+            out[at:at + size] = out[m0:m0 + size]
+        members.append((at, size))
+        at += size
+        pad = (-at) % 512
+        out[at:at + pad] = 0
+        at += pad
+    return out[:nbytes].tobytes()
+
+
 def stride_stream(nseg, seg_bytes, copy_bytes=None, seed=99):
     """S4 "stride" shape (BASELINE configs[3], scaled): `nseg` segments of noise (seed + segment index); in every
     4th segment the first `copy_bytes` (default a quarter) repeat the segment k segments earlier, k cycling

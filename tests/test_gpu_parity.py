@@ -394,16 +394,9 @@ def test_text_100m_bit_exact_vs_oracle(gpu_lib, oracle):
 
 
 def test_tar_like_1gib_bit_exact_vs_oracle(gpu_lib, oracle):
-    """1 GiB of the S3 tar mix (text and noise members, exact duplicates) against the oracle."""
-    parts, total, seed = [], 0, 11
-    while total < (1 << 30):
-        p = w.tar_like(64 << 20, seed=seed)
-        parts.append(p)
-        total += len(p)
-        seed += 1
-    # later blocks repeat earlier ones now and then: long matches at a distance of hundreds of MiB
-    data = b"".join(parts[:6] + [parts[1]] + parts[6:12] + [parts[3]] + parts[12:])[: 1 << 30]
-    _exact_vs_oracle(gpu_lib, oracle, data)
+    """1 GiB of the S3 tar mix (text and noise members, exact duplicates, repeats at distances of hundreds of MiB)
+    against the oracle."""
+    _exact_vs_oracle(gpu_lib, oracle, w.tar_like_fast(1 << 30, seed=11))
 
 
 @pytest.mark.parametrize("engine", ["wide", "narrow"])

@@ -11,6 +11,7 @@ if "noise64" in shapes: data["noise64"] = w.noise(64 << 20)
 if "text32" in shapes: data["text32"] = w.zipf_text(32 << 20)
 if "tar64" in shapes: data["tar64"] = w.tar_like(64 << 20)
 if "rep1g" in shapes: data["rep1g"] = w.rep64k_device(16384, "cuda")
+if "rep4g" in shapes: data["rep4g"] = w.rep64k_device(65536, "cuda")
 for lp in libs:
     lib = m.load_library(lp)
     row = {"lib": os.path.basename(lp)}
