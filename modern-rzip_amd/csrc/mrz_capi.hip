@@ -91,6 +91,8 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_crc_parts);
     hipFree(ctx->d_crc_out);
     if (ctx->d_gmailbox) hipFree(ctx->d_gmailbox);
+    if (ctx->d_seq_shared) hipFree(ctx->d_seq_shared);
+    if (ctx->d_wlog) hipFree(ctx->d_wlog);
     if (ctx->rz_scratch) hipFree(ctx->rz_scratch);
     if (ctx->d_rz_out) hipFree(ctx->d_rz_out);
     if (ctx->d_rz_done) hipFree(ctx->d_rz_done);
@@ -179,6 +181,13 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
             rc = MRZ_E_NOMEM;
         else
             ctx->d_gmailbox = p;
+    }
+    if (!rc) {
+        if (hipMalloc(&ctx->d_seq_shared, mrz_sequencer_shared_size()) != hipSuccess ||
+            hipMalloc((void **)&ctx->d_wlog, mrz_sequencer_wlog_size(ctx->nslots)) != hipSuccess)
+            rc = MRZ_E_NOMEM;
+        ctx->seq_wgs = 4;
+        if (const char *e = getenv("MRZ_SEQ_WGS")) ctx->seq_wgs = atoi(e);
     }
     if (!rc && max_chunk > 0) {
         rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, max_chunk / MRZ_MIN_MATCH + 2);
@@ -493,7 +502,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                              ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers));
         else
             STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                      ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers));
+                                      ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers, ctx->d_seq_shared, ctx->d_wlog,
+                                      ctx->nslots, ctx->seq_wgs));
         PROF_END();
         if (narrow) n_narrow++;
         STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -603,14 +613,16 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->hash_count = hs.count;
     res->n_events = E;
     if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[64] = { "batches", "formed", "committed", "segments", "emits", "backjump", "rewalk",
+        static const char *names[96] = { "batches", "formed", "committed", "segments", "emits", "backjump", "rewalk",
                                          "longres", "seq_cands", "cut_cplx", "cut_overflow", "skipout", "conf0", "pairs",
                                          "t_form", "t_walk", "t_conf", "t_pairs", "t_loop", "t_rewalk", "t_long", "t_seq",
                                          "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
                                          "f_fold", "s_tab", "s_pair", "s_ins", "ovl", "ovl_ok", "x_walk", "x_casc", "x_pool",
                                          "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw", "t_ovl",
-                                         "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit" };
-        for (int k = 0; k < 64; k++) if (names[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
+                                         "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit", "reprep", "w_stale", "w_drop", "reset",
+                                         "t_turn", "t_prep", "t_precommit", "e_mask", "e_cull", "e_xw", "e_inwin", "e_window", "e_bulk",
+                                         "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk" };
+        for (int k = 0; k < 96; k++) if (names[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

@@ -48,7 +48,7 @@ struct mrz_seq_state {
     int64_t hint_events;     // ... matches it emitted ...
     int64_t hint_matched;    // ... and the bytes those matches cover (most positions matched = one long match after another)
     int64_t pad[5];
-    int64_t prof[64];     // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
+    int64_t prof[96];     // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
 };
 
 // result of the record-sizing pass

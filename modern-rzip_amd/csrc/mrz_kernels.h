@@ -14,7 +14,10 @@ hipError_t mrz_launch_tagscan(hipStream_t stream, const uint8_t *buf, int64_t n,
                               const int64_t *hash_index, const mrz_seq_state *st, int64_t *tags, uint16_t *bitmap16);
 hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
                                 const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st, int64_t seg_start,
-                                int64_t seg_len, void *gmailbox, int n_helpers);
+                                int64_t seg_len, void *gmailbox, int n_helpers, void *wide_shared, unsigned *wlog,
+                                int64_t nslots, int seq_wgs);
+size_t mrz_sequencer_shared_size(void);
+size_t mrz_sequencer_wlog_size(int64_t nslots);
 hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
                                        const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st, int64_t seg_start,
                                        int64_t seg_len, void *gmailbox, int n_helpers);

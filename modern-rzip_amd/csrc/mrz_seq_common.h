@@ -57,6 +57,10 @@
 #else
 #define ST_ADD(k, v) ((void)0)
 #endif
+// the wide engine's write log: one batch stamp per 2^MRZ_WLOG_SHIFT table slots (4 slots = one 64-byte line)
+#ifndef MRZ_WLOG_SHIFT
+#define MRZ_WLOG_SHIFT 2
+#endif
 enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_EMITS, MRZ_ST_BACKJUMP, MRZ_ST_REWALK,
        MRZ_ST_LONGRES, MRZ_ST_SEQ, MRZ_ST_CUT_CPLX, MRZ_ST_CUT_OVERFLOW, MRZ_ST_SKIPOUT, MRZ_ST_CONF0, MRZ_ST_PAIRS,
        MRZ_ST_T_FORM, MRZ_ST_T_WALK, MRZ_ST_T_CONF, MRZ_ST_T_PAIRS, MRZ_ST_T_LOOP, MRZ_ST_T_REWALK, MRZ_ST_T_LONG,
@@ -64,7 +68,10 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        MRZ_ST_F_POST, MRZ_ST_F_WAIT, MRZ_ST_F_FOLD, MRZ_ST_S_TAB, MRZ_ST_S_PAIR, MRZ_ST_S_INS, MRZ_ST_OVL, MRZ_ST_OVL_OK,
        MRZ_ST_X_WALK, MRZ_ST_X_CASC, MRZ_ST_X_POOL, MRZ_ST_X_WIN, MRZ_ST_X_SAME, MRZ_ST_C_WIN, MRZ_ST_C_EVICT, MRZ_ST_C_DEEP,
        MRZ_ST_C_MANY, MRZ_ST_C_FAIL, MRZ_ST_C_TIE, MRZ_ST_C_NW, MRZ_ST_T_OVL, MRZ_ST_H_PRE, MRZ_ST_H_CAND, MRZ_ST_H_POST,
-       MRZ_ST_T_SCAN, MRZ_ST_T_FOLD, MRZ_ST_T_COMMIT, MRZ_ST_N };
+       MRZ_ST_T_SCAN, MRZ_ST_T_FOLD, MRZ_ST_T_COMMIT, MRZ_ST_REPREP, MRZ_ST_W_STALE, MRZ_ST_W_DROP, MRZ_ST_RESET,
+       MRZ_ST_T_TURN, MRZ_ST_T_PREP, MRZ_ST_T_PRECOMMIT, MRZ_ST_E_MASK, MRZ_ST_E_CULL, MRZ_ST_E_XW, MRZ_ST_E_INWIN,
+       MRZ_ST_E_WINDOW, MRZ_ST_E_BULK, MRZ_ST_E_MORE, MRZ_ST_T_PC_CW, MRZ_ST_T_PC_LOG, MRZ_ST_T_PC_BEST, MRZ_ST_T_PC_BULK,
+       MRZ_ST_N };
 
 struct mrz_seq_args {
     const uint8_t *buf;

@@ -60,8 +60,13 @@ struct mrz_wide_lds {
     int ctl[16];          // control words between wave 0 and the others
     int cmd;              // bumped by wave 0 for every command; the other waves wait on it
     int nb, total;        // lanes of the prepared batch; candidates in its bitmap window
-    int bulk_y, bulk_a1, bulk_a2, bulk_end;  // bulk commit done by the preparation: lanes [0, bulk_y), scan totals
+    int bulk_y, bulk_a1, bulk_a2, bulk_end;  // bulk commit done by the pre-commit step: lanes [first_live, bulk_y), totals
+    int first_live;       // first lane behind L.p
+    long long snap64[10];
+    mrz_lead lead;        // the matcher's state after a commit, for the waves that did not run it  // the snapshot a preparation works from (token, epoch, window base, masks)
+    int64_t prep_min_mask, prep_tag_mask;  // the masks the batch was prepared under
     int64_t cw_base, w_end, floor_prep;
+    int64_t adv_to, scan_last;  // see mrz_wide_prep
     int cw_len;
     // formation
     int pref[MRZ_W];
@@ -745,11 +750,10 @@ __device__ __forceinline__ int mrz_cw_slot(const mrz_wide_lds *S, int64_t cw_bas
 }
 
 struct mrz_wide_ret {
-    int used;        // candidates committed by this step
-    bool coop_next;  // the next candidate (the first after L.p) has to go through the cooperative path
-    bool ok;         // false: event list overflow
-    bool long_seen;  // a lane had entries beyond the 64-byte reach (scheduling hint)
-    bool skipped_out;  // an emitted match ended beyond the batch
+    int used;          // candidates committed by this step
+    bool ok;           // false: event list overflow
+    bool whole;        // every lane of the batch has been dealt with (committed, dropped or handed over)
+    bool stop_batch;   // the masks have moved / the cull window no longer holds: batches prepared ahead are void
 };
 
 // lane flags published for the committing wave
@@ -760,35 +764,37 @@ struct mrz_wide_ret {
 #define MRZ_LF_LONG 16
 #define MRZ_LF_REVS 32   // some entry has equal bytes before it: its result depends on how close last_match is
 
-// PREPARATION of one wide batch (phases A-C): all threads of the workgroup, identical L (read only) and width.
-// Leaves everything the commit needs in LDS; S->nb == 0 means the bitmap window held no candidate.
+// PREPARATION of one wide batch (phases A-C): all threads of the workgroup.  The batch is a WINDOW OF POSITIONS
+// [win_start, win_start + win_len) of the segment (win_start on a bitmap word, win_len <= 64 x threads): its
+// candidates, at most MRZ_W of them, one lane each.  Nothing here depends on the matcher's moving state except the
+// two masks (min_mask decides who is a candidate, tag_mask who inserts) and the table itself -- which may be BEHIND:
+// when several sequencer workgroups take turns, a batch is prepared while earlier batches are still being committed,
+// and the pre-commit step checks every lane against the log of blocks written since (mrz_wide_precommit).
+// Leaves everything the commit needs in LDS; S->nb == 0 means the window held no candidate.
 template <int NW>
-__device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wide_lds *S, const int64_t *__restrict__ tags,
+__device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const int64_t *__restrict__ tags,
                                      const mrz_u64 *__restrict__ bitmap, int64_t seg_start, int64_t lim, int64_t nwords,
-                                     int width, int tid, int lane, int wave, int64_t *stat) {
+                                     int64_t win_start, int win_len, int64_t min_pos, int64_t min_mask, int64_t tag_mask,
+                                     int tid, int lane, int wave, int64_t *stat) {
     constexpr int WT = 64 * NW;  // threads (= lanes of the batch at most) taking part
     const uint8_t *__restrict__ buf = C.buf;
-    mrz_slot *tab = C.tab;
     const int smask = (int)C.slot_mask;
-    const int max_chain = (int)C.max_chain;
-    const int64_t better = (L.min_mask << 1) | 1;
+    const int64_t better = (min_mask << 1) | 1;
     PROF_T0();
 
     // ---- A: formation ----------------------------------------------------------------------------------
-    int64_t pos = L.p + 1;
-    if (pos < seg_start) pos = seg_start;
-    const int64_t w0 = (pos - seg_start) >> 6;
+    const int64_t w0 = (win_start - seg_start) >> 6;
     const int64_t widx = w0 + tid;
-    mrz_u64 w = widx < nwords ? bitmap[widx] : 0ull;
+    mrz_u64 w = (tid * 64 < win_len && widx < nwords) ? bitmap[widx] : 0ull;
     {
         const int64_t lane_lo = seg_start + widx * 64;
-        if (pos > lane_lo) {
-            const int64_t sh = pos - lane_lo;
-            w = sh >= 64 ? 0ull : (w >> sh) << sh;
-        }
         if (lim < lane_lo + 63) {
             const int64_t keepbits = lim - lane_lo + 1;
             w = keepbits <= 0 ? 0ull : (w & mrz_low_mask((int)keepbits));
+        }
+        if (min_pos > lane_lo) {  // the epoch begins inside this word
+            const int64_t drop = min_pos - lane_lo;
+            w = drop >= 64 ? 0ull : (w & ~mrz_low_mask((int)drop));
         }
     }
     for (int i = tid; i < MRZ_BH_SIZE; i += WT) {
@@ -804,71 +810,75 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
     S->nchunk[tid] = 0;
     S->supp_w[tid] = (unsigned short)MRZ_W;
     S->supp_w2[tid] = (unsigned short)MRZ_W;
-    // the cull window: entries ahead of tag_clean_ptr that fail `better` (only when this batch can reach the limit)
-    const int64_t cw_base = L.clean_ptr;
-    const bool want_cw = L.count + width > C.limit;
-    const int cw_len = want_cw ? MRZ_CW_WORDS * 64 : 0;
-    if (want_cw) {
-        for (int b = 0; b < MRZ_CW_WORDS / NW; b++) {
-            const int wi = b * NW + wave;
-            const int64_t slot = cw_base + (int64_t)wi * 64 + lane;
-            mrz_slot e;
-            e.off = 0;
-            e.t = 0;
-            if (slot < C.nslots) e = tab[slot];
-            const mrz_u64 m = __ballot(((e.off | e.t) != 0) && ((e.t & better) != better));
-            if (lane == 0) S->cw[wi] = m;
-        }
-    } else if (tid < MRZ_CW_WORDS)
-        S->cw[tid] = 0ull;
+    const int64_t cw_base = 0;  // the cull window is the pre-commit step's business
+    const int cw_len = 0;
     const int cnt = __popcll(w);
-    int total;
-    const int incl = mrz_wide_incl<NW>(cnt, S->wt1, lane, wave, &total);
+    int total_raw;
+    const int incl = mrz_wide_incl<NW>(cnt, S->wt1, lane, wave, &total_raw);
     S->pref[tid] = incl - cnt;
     S->word[tid] = w;
     mrz_prep_sync<NW>();
-    if (wave == 0) {
-        const int c = lane < MRZ_CW_WORDS ? __popcll(S->cw[lane]) : 0;
-        const int ci = mrz_wave_incl_sum(c, lane);
-        if (lane < MRZ_CW_WORDS) S->cwcum[lane + 1] = ci;
-        if (lane == 0) S->cwcum[0] = 0;
-    }
-    const int nb = total < width ? total : width;
-    if (tid == 0) {
-        const int64_t wend = seg_start + (w0 + WT) * 64 - 1;
-        S->nb = nb;
-        S->total = total;
-        S->cw_base = cw_base;
-        S->cw_len = cw_len;
-        S->w_end = wend < lim ? wend : lim;
-        S->floor_prep = L.last_match > 0 ? L.last_match : 0;
-    }
-    if (nb == 0) {
-        mrz_prep_sync<NW>();
-        return;
-    }
-    const bool have = tid < nb;
-    mrz_prep_sync<NW>();  // cwcum is complete
-    for (int r = tid; r < MRZ_W; r += WT)
-        if (r < S->cwcum[MRZ_CW_WORDS]) S->cw_list[r] = mrz_cw_slot_search(S, cw_base, r);
-    int64_t q = 0, t = 0;
-    {
+    // The bitmap was made under the mask of the time of the tag scan (a launch or two ago): some of its candidates no
+    // longer pass min_mask.  Every thread examines two of them (neighbours, so that the order stays the positions'),
+    // the ones that pass are compacted into the lanes.
+    const int raw_cap = 2 * WT;
+    const int nraw = total_raw < raw_cap ? total_raw : raw_cap;
+    int64_t qr[2] = { 0, 0 }, tr[2] = { 0, 0 };
+    bool ar[2] = { false, false };
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int r = 2 * tid + e;
         int wlo = 0, whi = WT - 1;
         for (int it = 0; (1 << it) < WT; it++) {
             const int mid = (wlo + whi + 1) >> 1;
-            if (S->pref[mid] <= tid)
+            if (S->pref[mid] <= r)
                 wlo = mid;
             else
                 whi = mid - 1;
         }
-        if (have) {
-            q = seg_start + (w0 + wlo) * 64 + mrz_select64(S->word[wlo], tid - S->pref[wlo]);
-            t = tags[q - seg_start];
+        if (r < nraw) {
+            qr[e] = seg_start + (w0 + wlo) * 64 + mrz_select64(S->word[wlo], r - S->pref[wlo]);
+            tr[e] = tags[qr[e] - seg_start];
+            ar[e] = (tr[e] & min_mask) == min_mask;
+            if (r == nraw - 1) S->scan_last = qr[e];
         }
     }
-    const bool act = have && (t & L.min_mask) == L.min_mask;
-    bool ins = act && (t & L.tag_mask) == L.tag_mask;
-    const bool loose = L.tag_mask != better;
+    int total;
+    const int cnt_a = (ar[0] ? 1 : 0) + (ar[1] ? 1 : 0);
+    const int incl_a = mrz_wide_incl<NW>(cnt_a, S->wt3, lane, wave, &total);
+    {
+        const int base = incl_a - cnt_a;
+        if (ar[0] && base < MRZ_W) {
+            S->q[base] = qr[0];
+            S->t[base] = tr[0];
+        }
+        const int b1 = base + (ar[0] ? 1 : 0);
+        if (ar[1] && b1 < MRZ_W) {
+            S->q[b1] = qr[1];
+            S->t[b1] = tr[1];
+        }
+    }
+    const int nb = total < MRZ_W ? total : MRZ_W;
+    mrz_prep_sync<NW>();
+    if (tid == 0) {
+        const int64_t wend0 = win_start + win_len - 1;
+        const int64_t wend = wend0 < lim ? wend0 : lim;
+        S->nb = nb;
+        S->total = total;  // > nb: more candidates than a batch has lanes
+        S->w_end = wend;
+        // how far the matcher may move once every lane has been committed: nowhere beyond the last lane when candidates
+        // were left out, to the last one examined when the window held more than could be examined, else to its end
+        S->adv_to = total > MRZ_W ? (int64_t)-1 : (total_raw > raw_cap ? S->scan_last : wend);
+        S->prep_min_mask = min_mask;
+        S->prep_tag_mask = tag_mask;
+    }
+    const bool have = tid < nb;
+    const int64_t q = have ? S->q[tid] : 0, t = have ? S->t[tid] : 0;
+    mrz_prep_sync<NW>();
+    if (nb == 0) return;
+    const bool act = have && (t & min_mask) == min_mask;
+    bool ins = act && (t & tag_mask) == tag_mask;
+    const bool loose = tag_mask != better;
     S->q[tid] = have ? q : (int64_t)0x7fffffffffffffffll;
     PROF_ADD(MRZ_ST_T_FORM);
 
@@ -1164,53 +1174,188 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
     }
 #endif
 
-    // ---- what the committing wave needs of this lane ------------------------------------------------------------
+    // ---- what the pre-commit step needs of this lane (the rest is in the per-lane arrays already) --------------------
     {
-        const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
-        int64_t bl = 0, bo = 0;
-        int br = 0, bh = 0, bm = 0;
-        bool lng = false;
-        if (act && !cplx && !conf)
-            mrz_lane_best(S, tid, wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX, q, floor_p, &bl, &bo, &br, &bh, &bm, &lng);
-        S->blen[tid] = bl;
-        S->boff[tid] = bo;
-        S->brev[tid] = br;
-        S->bhm[tid] = (unsigned short)((bh << 8) | bm);
-        S->dep0[tid] = (unsigned short)(dep0 >= 0 ? dep0 : MRZ_W);
-        S->dep1[tid] = (unsigned short)(dep1 >= 0 ? dep1 : MRZ_W);
-        S->dep2[tid] = (unsigned short)(dep2 >= 0 ? dep2 : MRZ_W);
-        S->len1[tid] = (act && !cplx) ? len1 : 0;
-        S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
         bool revs = false;
         if (act && !cplx && !conf) {
             const int nsx = wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX;
             for (int k = 0; k < nsx; k++) revs = revs || ((S->pool[S->chunk_id[tid][k >> 2]].raw[k & 3] >> 8) & 127) != 0;
         }
+        S->dep0[tid] = (unsigned short)(dep0 >= 0 ? dep0 : MRZ_W);
+        S->dep1[tid] = (unsigned short)(dep1 >= 0 ? dep1 : MRZ_W);
+        S->dep2[tid] = (unsigned short)(dep2 >= 0 ? dep2 : MRZ_W);
+        S->len1[tid] = (act && !cplx) ? len1 : 0;
+        S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
         S->lf[tid] = (unsigned char)((conf ? MRZ_LF_CONF : 0) | (cplx ? MRZ_LF_CPLX : 0) | (act ? MRZ_LF_ACT : 0) |
-                                     (ins ? MRZ_LF_INS : 0) | (lng ? MRZ_LF_LONG : 0) | (revs ? MRZ_LF_REVS : 0));
+                                     (ins ? MRZ_LF_INS : 0) | (revs ? MRZ_LF_REVS : 0));
+    }
+    mrz_prep_sync<NW>();
+}
 
-        // ---- E0: bulk commit.  The leading lanes up to the first one that is stale, complex or has a match to fold
-        // need none of the lazy-match logic (no match can be adopted or emitted among them when none is pending):
-        // all waves commit them at once -- scans for victim_round, hash_count and the cull ranks as in the commit
-        // proper -- and hand wave 0 the totals.  Match-free stretches (noise) are committed entirely here.
+// PRE-COMMIT of a prepared batch: all threads of the workgroup, once the matcher's state L is this workgroup's to move
+// (its turn has come).  Brings the prepared lanes up to date with what has happened since they were prepared:
+//   * lanes at or before L.p are dropped (an emitted match covers them);
+//   * a lane whose read ranges touch a block of table slots written after `snap` (the number of batches that had been
+//     committed when the preparation began; wlog[block] = 1 + the batch that wrote it last) is stale;
+//   * the cull window -- the failing entries ahead of tag_clean_ptr (clean_one_from_hash, src/rzip.c:313-321) -- is
+//     loaded now; lanes that read inside it are stale, lanes whose insert would change it are complex;
+//   * every lane's best match under the current last_match;
+// then the bulk commit (E0): the leading lanes up to the first one that is stale, complex or has a match to fold need
+// none of the lazy-match logic (no match can be adopted or emitted among them when none is pending): all waves commit
+// them at once -- scans for victim_round, hash_count and the cull ranks as in the commit proper -- and hand wave 0 the
+// totals.  Match-free stretches (noise) are committed entirely here.
+template <int NW>
+__device__ static void mrz_wide_precommit(const mrz_cfg &C, const mrz_lead &L, mrz_wide_lds *S, unsigned *__restrict__ wlog,
+                                          unsigned snap, unsigned batch_no, int tid, int lane, int wave, int64_t *stat) {
+    mrz_slot *tab = C.tab;
+    const int smask = (int)C.slot_mask;
+    const int max_chain = (int)C.max_chain;
+    const int64_t better = (L.min_mask << 1) | 1;
+    const bool loose = L.tag_mask != better;
+    const int nb = S->nb;
+    if (nb == 0) {
+        if (tid == 0) S->bulk_y = 0;
+        mrz_prep_sync<NW>();
+        return;
+    }
+    PROF_T0();
+    // ---- this lane, from what its preparation has published
+    const bool have = tid < nb;
+    const int f0 = have ? S->lf[tid] : 0;
+    const int64_t q = S->q[tid < MRZ_W ? tid : 0];
+    const bool live = have && q > L.p;  // not covered by a match emitted since
+    const bool act = live && (f0 & MRZ_LF_ACT);
+    const bool ins = act && (f0 & MRZ_LF_INS);
+    bool cplx = act && (f0 & MRZ_LF_CPLX), conf = act && (f0 & MRZ_LF_CONF);
+    const int h = S->h[tid], len1 = S->len1[tid], h2 = S->h2[tid], len2 = S->len2[tid];
+    const int kind = S->kind[tid], kind2 = S->kind2[tid];
+    const int wslot0 = S->wslot[tid], w2 = S->w2[tid];
+    if (act && !cplx && !conf) {
+        // an overlay walk that has assumed the writes of a lane that is not going to run (the matcher is past it)
+        const int d0 = S->dep0[tid], d1 = S->dep1[tid], d2 = S->dep2[tid];
+        if ((d0 < MRZ_W && S->q[d0] <= L.p) || (d1 < MRZ_W && S->q[d1] <= L.p) || (d2 < MRZ_W && S->q[d2] <= L.p)) conf = true;
+    }
+    ST_COUNT(MRZ_ST_W_DROP, have && !live);
+    const bool conf_before = conf;
+    (void)conf_before;
+    // written since the preparation began?  The log entries of the ends of the two read ranges are asked for now and
+    // looked at after the cull window has been loaded (one trip to memory for both)
+    const bool ask_log = act && !cplx && !conf && snap < batch_no;
+    const int lmask = smask >> MRZ_WLOG_SHIFT;
+    const int b1a = h >> MRZ_WLOG_SHIFT, b1b = ((h + (len1 > 0 ? len1 - 1 : 0)) & smask) >> MRZ_WLOG_SHIFT;
+    const int b2a = h2 >> MRZ_WLOG_SHIFT, b2b = ((h2 + (len2 > 0 ? len2 - 1 : 0)) & smask) >> MRZ_WLOG_SHIFT;
+    unsigned g1a = 0, g1b = 0, g2a = 0, g2b = 0;
+    if (ask_log && len1 > 0) {
+        g1a = wlog[b1a & lmask];
+        g1b = wlog[b1b];
+    }
+    if (ask_log && len2 > 0) {
+        g2a = wlog[b2a & lmask];
+        g2b = wlog[b2b];
+    }
+
+    // the cull window (only when this batch can reach the limit)
+    const int64_t cw_base = L.clean_ptr;
+    const bool want_cw = L.count + nb > C.limit;
+    const int cw_len = want_cw ? MRZ_CW_WORDS * 64 : 0;
+    if (want_cw) {
+        for (int b = 0; b < MRZ_CW_WORDS / NW; b++) {
+            const int wi = b * NW + wave;
+            const int64_t slot = cw_base + (int64_t)wi * 64 + lane;
+            mrz_slot e;
+            e.off = 0;
+            e.t = 0;
+            if (slot < C.nslots) e = tab[slot];
+            const mrz_u64 m = __ballot(((e.off | e.t) != 0) && ((e.t & better) != better));
+            if (lane == 0) S->cw[wi] = m;
+        }
+    } else if (tid < MRZ_CW_WORDS)
+        S->cw[tid] = 0ull;
+    if (tid == 0) {
+        S->cw_base = cw_base;
+        S->cw_len = cw_len;
+        S->floor_prep = L.last_match > 0 ? L.last_match : 0;
+    }
+    mrz_prep_sync<NW>();
+    if (wave == 0) {
+        const int c = lane < MRZ_CW_WORDS ? __popcll(S->cw[lane]) : 0;
+        const int ci = mrz_wave_incl_sum(c, lane);
+        if (lane < MRZ_CW_WORDS) S->cwcum[lane + 1] = ci;
+        if (lane == 0) S->cwcum[0] = 0;
+    }
+    mrz_prep_sync<NW>();
+    for (int r = tid; r < MRZ_W; r += 64 * NW)
+        if (r < S->cwcum[MRZ_CW_WORDS]) S->cw_list[r] = mrz_cw_slot_search(S, cw_base, r);
+    PROF_ADD(MRZ_ST_T_PC_CW);
+
+    if (ask_log) {
+        if (g1a > snap || g1b > snap || g2a > snap || g2b > snap) conf = true;
+        // (ranges of more than two log blocks: the ones in between)
+        for (int part = 0; part < 2 && !conf; part++) {
+            const int ba = part ? b2a : b1a, bb = part ? b2b : b1b, rl = part ? len2 : len1;
+            if (rl <= 0 || ba == bb) continue;
+            for (int blk = (ba + 1) & lmask; blk != bb; blk = (blk + 1) & lmask)
+                if (wlog[blk] > snap) conf = true;
+        }
+    }
+    if (act && !cplx && !conf) {
+        // a write that changes the set of failing entries inside the window would change the sweep; reads inside the
+        // window: an earlier lane's cull may empty a slot this lane has read
+        if (cw_len > 0) {
+            if (ins) {
+                if ((kind == 1 || loose) && kind != 3 && wslot0 >= cw_base && wslot0 < cw_base + cw_len) cplx = true;
+                if (kind == 2 && (kind2 == 1 || loose) && w2 >= cw_base && w2 < cw_base + cw_len) cplx = true;
+            }
+            if (mrz_ranges_meet(h, len1, (int)cw_base, cw_len, smask) || mrz_ranges_meet(h2, len2, (int)cw_base, cw_len, smask))
+                conf = true;
+        }
+    }
+    ST_COUNT(MRZ_ST_W_STALE, conf && !conf_before);
+    PROF_ADD(MRZ_ST_T_PC_LOG);
+    {
+        const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
+        int64_t bl = 0, bo = 0;
+        int br = 0, bh = 0, bm = 0;
+        bool lng = false;
+        if (act && !cplx && !conf) mrz_lane_best(S, tid, S->ns[tid], q, floor_p, &bl, &bo, &br, &bh, &bm, &lng);
+        S->blen[tid] = bl;
+        S->boff[tid] = bo;
+        S->brev[tid] = br;
+        S->bhm[tid] = (unsigned short)((bh << 8) | bm);
+        if (have) {
+            S->lf[tid] = (unsigned char)((conf ? MRZ_LF_CONF : 0) | (cplx ? MRZ_LF_CPLX : 0) | (act ? MRZ_LF_ACT : 0) |
+                                         (ins ? MRZ_LF_INS : 0) | (lng ? MRZ_LF_LONG : 0) | (f0 & MRZ_LF_REVS));
+            if (!live) S->exec[tid] = 2;
+        }
+
+        PROF_ADD(MRZ_ST_T_PC_BEST);
+        // ---- E0: bulk commit
         const bool stopish = have && act && (cplx || conf || lng || bl > 0);
         {
-            const int f = mrz_wave_first(stopish, wave, nb);
-            if (lane == 0) S->wmin[0][wave] = f;
+            const int fs = mrz_wave_first(stopish, wave, nb);
+            const int fl = mrz_wave_first(live, wave, nb);
+            if (lane == 0) {
+                S->wmin[0][wave] = fs;
+                S->wmin[3][wave] = fl;
+            }
         }
         mrz_prep_sync<NW>();
-        int x0 = S->wmin[0][0];
+        int x0 = S->wmin[0][0], s0 = S->wmin[3][0];
 #pragma unroll
-        for (int w = 1; w < NW; w++) x0 = S->wmin[0][w] < x0 ? S->wmin[0][w] : x0;
+        for (int w = 1; w < NW; w++) {
+            x0 = S->wmin[0][w] < x0 ? S->wmin[0][w] : x0;
+            s0 = S->wmin[3][w] < s0 ? S->wmin[3][w] : s0;
+        }
         if (L.cur_len >= MRZ_MIN_MATCH) x0 = 0;  // a pending match may be emitted at any lane
-        if (x0 >= MRZ_BULK_MIN) {
-            const bool inb = tid < x0;
+        if (tid == 0) S->first_live = s0;
+        if (x0 - s0 >= MRZ_BULK_MIN) {
+            const bool inb = tid >= s0 && tid < x0;
             const bool a_ins = inb && ins;
-            const bool a_ev = a_ins && wl.kind == 3;
-            const int d = a_ins ? (wl.kind == 0 ? 1 : (wl.kind == 2 ? (wl.kind2 == 0 ? 1 : 0) : 0)) : 0;
+            const bool a_ev = a_ins && kind == 3;
+            const int d = a_ins ? (kind == 0 ? 1 : (kind == 2 ? (kind2 == 0 ? 1 : 0) : 0)) : 0;
             int dummy;
             const int i1 = mrz_wide_incl<NW>(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wt1, lane, wave, &dummy);
-            int wslot = wl.wslot;
+            int wslot = wslot0;
             if (a_ev) {
                 const int er = ((i1 >> 10) & 1023) - 1;
                 const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
@@ -1254,47 +1399,53 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, const mrz_lead &L, mrz_wi
                 y = c_lane + 1;
                 endb = true;
             }
-            if (tid < y) {
+            if (tid >= s0 && tid < y) {
                 if (a_ins) {
-                    if (wl.kind == 2 && S->supp_w2[tid] >= y) {
+                    const unsigned stamp = batch_no + 1u;
+                    if (kind == 2 && S->supp_w2[tid] >= y) {
                         mrz_slot oc;
-                        oc.off = wl.occ_off;
-                        oc.t = wl.occ_t;
-                        tab[wl.w2] = oc;
+                        oc.off = S->occ_off[tid];
+                        oc.t = S->occ_t[tid];
+                        tab[w2] = oc;
+                        wlog[w2 >> MRZ_WLOG_SHIFT] = stamp;
                     }
                     if (S->supp_w[tid] >= y) {
                         mrz_slot nw;
                         nw.off = q;
-                        nw.t = t;
+                        nw.t = S->t[tid];
                         tab[wslot] = nw;
+                        wlog[wslot >> MRZ_WLOG_SHIFT] = stamp;
                     }
                     if (cslot >= 0) {
                         mrz_slot z;
                         z.off = 0;
                         z.t = 0;
                         tab[cslot] = z;
+                        wlog[cslot >> MRZ_WLOG_SHIFT] = stamp;
                     }
                 }
                 S->exec[tid] = 1;
             }
-            if (y > 0 && tid == y - 1) {
+            if (y > s0 && tid == y - 1) {
                 S->bulk_a1 = i1;
                 S->bulk_a2 = i2;
             }
             if (tid == 0) {
-                S->bulk_y = y;
+                S->bulk_y = y > s0 ? y : 0;
                 S->bulk_end = endb ? 1 : 0;
             }
         } else if (tid == 0)
             S->bulk_y = 0;
     }
     mrz_prep_sync<NW>();
+    PROF_ADD(MRZ_ST_T_PC_BULK);
 }
 
 // COMMIT of a prepared batch (phase E): wave 0 alone, no workgroup barrier.  Windows of up to 64 lanes starting at the
 // first lane not yet dealt with; a window is cut at the first lane that cannot be committed as prepared.
-__device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds *S, int lane, int64_t *stat,
-                                       mrz_wide_ret *ret) {
+__device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_lds *S, unsigned *__restrict__ wlog,
+                                       unsigned batch_no, int lane, int64_t *stat, mrz_wide_ret *ret) {
+    const unsigned stamp = batch_no + 1u;  // what this batch leaves in the write log
     mrz_slot *tab = C.tab;
     const int smask = (int)C.slot_mask;
     const int max_chain = (int)C.max_chain;
@@ -1305,20 +1456,16 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
     const int cw_len = mrz_uni(S->cw_len);
     const int64_t floor_prep = mrz_uni64(S->floor_prep);
     ret->used = 0;
-    ret->coop_next = false;
     ret->ok = true;
-    ret->long_seen = false;
-    ret->skipped_out = false;
+    ret->whole = true;
+    ret->stop_batch = false;
+    (void)total;
     PROF_T0();
-    if (nb == 0) {
-        const int64_t we = mrz_uni64(S->w_end);
-        if (we > L.p) L.p = we;
-        return;
-    }
-    int s = 0, cw_used = 0, committed = 0, iters = 0;
+    if (nb == 0) return;
+    int s = mrz_uni(S->first_live), cw_used = 0, committed = 0, iters = 0;
     bool bulk_end = false;
     {
-        // what the preparation has committed in bulk already: lanes [0, y)
+        // what the pre-commit step has committed in bulk already: lanes [first_live, y)
         const int y = mrz_uni(S->bulk_y);
         if (y > 0) {
             const int a1 = mrz_uni(S->bulk_a1), a2 = mrz_uni(S->bulk_a2);
@@ -1336,7 +1483,7 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             if (esum) L.victim_round = (int64_t)(((unsigned)L.victim_round + (unsigned)esum) % (unsigned)max_chain);
             L.tag_misses += msum;
             L.p = mrz_uni64(S->q[y - 1]);
-            committed = y;
+            committed = y - s;
             s = y;
             bulk_end = mrz_uni(S->bulk_end) != 0;
             ST_ADD(MRZ_ST_SEGMENTS, 1);
@@ -1430,26 +1577,38 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                 const int nwx = mrz_uni(S->coop.n_written);
                 const int64_t cullx = mrz_uni64(S->coop.cull_slot);
                 bool stop_batch = L.min_mask != pre_min || L.tag_mask != pre_tag;
+                ST_ADD(MRZ_ST_E_MASK, stop_batch ? 1 : 0);
                 // its cull must be the one the window expects next; its insert must not have touched the window
                 if (cullx >= 0) {
-                    if (cw_len == 0 || cw_used >= S->cwcum[MRZ_CW_WORDS] || mrz_cw_slot(S, cw_base, cw_used) != (int)cullx)
+                    if (cw_len == 0 || cw_used >= S->cwcum[MRZ_CW_WORDS] || mrz_cw_slot(S, cw_base, cw_used) != (int)cullx) {
                         stop_batch = true;
-                    else
+                        ST_ADD(MRZ_ST_E_CULL, 1);
+                    } else
                         cw_used++;
                 }
                 int nx = mrz_uni(S->xw_n);
-                if (nx + nwx + 1 > MRZ_XW_MAX)
+                if (nx + nwx + 1 > MRZ_XW_MAX) {
+                    ST_ADD(MRZ_ST_E_XW, 1);
                     stop_batch = true;
-                else {
+                    if (lane < nwx) wlog[S->coop.pend_h[lane] >> MRZ_WLOG_SHIFT] = stamp;
+                    if (cullx >= 0 && lane == 0) wlog[cullx >> MRZ_WLOG_SHIFT] = stamp;
+                } else {
                     // its writes: the lanes behind it look at them when their window comes up
                     if (lane < nwx) {
                         const int64_t hs = S->coop.pend_h[lane];
                         S->xw_slot[nx + lane] = (int)hs;
+                        wlog[hs >> MRZ_WLOG_SHIFT] = stamp;
                     }
-                    if (cullx >= 0 && lane == 0) S->xw_slot[nx + nwx] = (int)cullx;
+                    if (cullx >= 0 && lane == 0) {
+                        S->xw_slot[nx + nwx] = (int)cullx;
+                        wlog[cullx >> MRZ_WLOG_SHIFT] = stamp;
+                    }
                     const bool inwin = lane < nwx && cw_len > 0 && S->coop.pend_h[lane] >= cw_base &&
                                        S->coop.pend_h[lane] < cw_base + cw_len;
-                    if (__ballot(inwin)) stop_batch = true;
+                    if (__ballot(inwin)) {
+                        stop_batch = true;
+                        ST_ADD(MRZ_ST_E_INWIN, 1);
+                    }
                     nx += nwx + (cullx >= 0 ? 1 : 0);
                     if (lane == 0) S->xw_n = nx;
                 }
@@ -1468,10 +1627,7 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                         }
                         s_next = lo;
                         for (int k = s + 1 + lane; k < s_next; k += 64) S->exec[k] = 2;  // dropped
-                        if (s_next >= nb) {
-                            ret->skipped_out = true;
-                            ST_ADD(MRZ_ST_SKIPOUT, 1);
-                        }
+                        if (s_next >= nb) ST_ADD(MRZ_ST_SKIPOUT, 1);
                     } else {
                         ST_ADD(MRZ_ST_BACKJUMP, 1);
                         s_next = s;  // comes by q_e again, after its own insert: the cooperative path once more
@@ -1481,13 +1637,15 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                 MRZ_WAVE_SYNC();
                 s = s_next;
                 PROF_ADD(MRZ_ST_H_POST);
-                if (stop_batch) break;
+                if (stop_batch) {
+                    ret->stop_batch = true;
+                    break;
+                }
                 continue;
             }
             // tag-equal entries beyond the 64-byte reach: measured exactly (striped rounds, compare farm) and folded
             // in probe order
             ST_ADD(MRZ_ST_LONGRES, 1);
-            ret->long_seen = true;
             const int nsx = mrz_uni(S->ns[s]);
             const int64_t qx = mrz_uni64(S->q[s]);
             if (lane < nsx) {
@@ -1581,11 +1739,13 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             end_batch = loose && c_lane + 1 <= y;
         }
         if (y == 0) {
-            // the very next lane cannot be served from the cull window: a fresh batch reloads it; if even a fresh
-            // window has nothing (sweep wrap, mask promotion) the cooperative path takes the candidate
-            if (s == 0 && cw_used == 0) ret->coop_next = true;
+            // the very next lane cannot be served from the cull window (it is used up, or the sweep wraps / the mask
+            // is promoted): the lane is marked complex and goes through the cooperative path in the next iteration;
+            // the window is void after that
             ST_ADD(MRZ_ST_CUT_OVERFLOW, 1);
-            break;
+            if (lane == 0) S->lf[s] = (unsigned char)(S->lf[s] | MRZ_LF_CPLX);
+            MRZ_WAVE_SYNC();
+            continue;
         }
         PROF_ADD(MRZ_ST_T_SCAN);
 
@@ -1595,19 +1755,23 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                 mrz_slot oc;
                 oc.off = S->occ_off[ii];
                 oc.t = S->occ_t[ii];
-                tab[S->w2[ii]] = oc;
+                const int w2s = S->w2[ii];
+                tab[w2s] = oc;
+                wlog[w2s >> MRZ_WLOG_SHIFT] = stamp;
             }
             if (S->supp_w[ii] >= s + y) {
                 mrz_slot nw;
                 nw.off = q;
                 nw.t = S->t[ii];
                 tab[wslot] = nw;
+                wlog[wslot >> MRZ_WLOG_SHIFT] = stamp;
             }
             if (cslot >= 0) {
                 mrz_slot z;
                 z.off = 0;
                 z.t = 0;
                 tab[cslot] = z;
+                wlog[cslot >> MRZ_WLOG_SHIFT] = stamp;
             }
         }
         if (lane < y) S->exec[ii] = 1;
@@ -1676,10 +1840,7 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                 }
                 s_next = lo;
                 for (int k = s + y + lane; k < s_next; k += 64) S->exec[k] = 2;
-                if (s_next >= nb) {
-                    ret->skipped_out = true;
-                    ST_ADD(MRZ_ST_SKIPOUT, 1);
-                }
+                if (s_next >= nb) ST_ADD(MRZ_ST_SKIPOUT, 1);
             } else {
                 // the match ends before the emitting position: the loop goes BACK (p = last_match, :596) and comes
                 // by q_e again -- the only candidate of (last_match, q_e] -- after its own insert
@@ -1694,13 +1855,17 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
         MRZ_WAVE_SYNC();
         s = s_next;
         PROF_ADD(MRZ_ST_T_COMMIT);
-        if (end_batch) break;
+        if (end_batch) {
+            ST_ADD(MRZ_ST_E_WINDOW, 1);
+            ret->stop_batch = true;
+            break;
+        }
     }
-    // the window ran dry: skip its empty rest
-    if (ret->ok && !ret->coop_next && s >= nb && nb == total) {
-        const int64_t we = mrz_uni64(S->w_end);
-        if (we > L.p) L.p = we;
+    if (bulk_end) {
+        ST_ADD(MRZ_ST_E_BULK, 1);
+        ret->stop_batch = true;
     }
+    ret->whole = s >= nb && !ret->stop_batch;
     ST_ADD(MRZ_ST_COMMITTED, committed);
     ret->used = committed;
 }

@@ -25,22 +25,89 @@
 // Bound: latency -- a chain of dependent table probes, data probes and cross-CU hand-offs; DESIGN.md 4.2.
 #include "mrz_seq_wide.h"
 
-__global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_args a) {
-    __shared__ mrz_wide_lds wide;
+// ---- several sequencer workgroups taking turns ---------------------------------------------------------------
+// The preparation of a batch (walks, conflicts, overlay walks, match probes) is most of its cost and only READS the
+// table, so it can run while earlier batches are still being committed.  Up to MRZ_SEQ_WGS sequencer workgroups --
+// all on ONE XCD, so that they share an L2 (blocks 0, 8, 16, ...: checked at run time through HW_REG_XCC_ID) -- take
+// the batches of the position stream round robin: batch b is a window of positions fixed by (epoch base, b); workgroup
+// j prepares its batch against the table as it sees it, then waits for its TURN (token == b in device memory),
+// brings the prepared lanes up to date (mrz_wide_precommit: a lane that read a 64-slot block written since the
+// preparation began is stale), commits, writes the matcher state back and passes the token on.  Commits are strictly
+// in batch order, so the result is the one workgroup's result.  Whenever a batch does not end where the next window
+// begins (a match swallowed the following windows, the masks moved, a window overflowed its 512 lanes) the committer
+// opens a new epoch: windows are re-based at the matcher's position and batches prepared under the old epoch are
+// prepared again when their turn comes.
+#ifndef MRZ_SEQ_WGS
+#define MRZ_SEQ_WGS 4
+#endif
+#define MRZ_TURN_SPIN_LIMIT (1ll << 27)
 
+struct mrz_wide_shared {          // device memory, zeroed by the host before every launch
+    unsigned long long token;     // batches committed so far = the batch whose turn it is
+    unsigned long long quit;      // the launch is over (segment end, error)
+    unsigned long long census;    // sequencer workgroups that have reported their XCC id
+    unsigned long long n_active;  // set by workgroup 0 once the state below is valid: workgroups taking part
+    int xcc[8];
+    int active[8];                // compact index of sequencer workgroup j, or -1
+    // handed from committer to committer (plain stores before the token is released)
+    mrz_lead L;
+    unsigned long long gseq;
+    long long farm_hint;
+    int gnw, pw;                  // pw: bitmap words per batch window
+    int small_run, pad_;          // batches in a row that came out less than half full
+    long long epoch, base_word, base_batch;  // batch b covers words [base_word + (b - base_batch) * pw, + pw)
+    long long base_pos;                      // ... and nothing before this position (where the epoch began)
+};
+
+#ifdef __HIP_DEVICE_COMPILE__
+#define MRZ_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define MRZ_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define MRZ_XCC_ID() (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15)
+#else
+#define MRZ_ACQUIRE_AGENT() ((void)0)
+#define MRZ_RELEASE_AGENT() ((void)0)
+#define MRZ_XCC_ID() 0
+#endif
+
+__device__ __forceinline__ int mrz_words_per_batch(int64_t min_mask) {
+    // candidates are 2^-k of the positions (k mask bits): aim at 7/8 of the lanes, whole bitmap words
+    const int k = __popcll((unsigned long long)min_mask);
+    long long pos = (long long)(MRZ_W * 7 / 8) << (k < 20 ? k : 20);
+    long long wds = pos / 64;
+    if (wds > MRZ_W) wds = MRZ_W;
+    return (int)(wds < 1 ? 1 : wds);
+}
+
+__global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_args a, mrz_wide_shared *G,
+                                                                        unsigned *wlog, int want_wgs) {
+#ifdef MRZ_EMU_LDS_PER_BLOCK
+    // (the CPU emulator of the test suite keeps `__shared__` in one static copy: one per sequencer workgroup here)
+    static mrz_wide_lds wide_all[MRZ_SEQ_WGS];
+    mrz_wide_lds *S = &wide_all[(blockIdx.x / 8) % MRZ_SEQ_WGS];
+#else
+    __shared__ mrz_wide_lds wide;
+    mrz_wide_lds *S = &wide;
+#endif
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = mrz_uni(tid >> 6);
     mrz_seq_state *st = a.st;
-    mrz_wide_lds *S = &wide;
 
     if (st->finished || st->error) return;
+    // which role: blocks 0, 8, 16, ... are sequencer workgroups (one XCD), the others compare-farm helpers
+    int wgs = want_wgs < 1 ? 1 : (want_wgs > MRZ_SEQ_WGS ? MRZ_SEQ_WGS : want_wgs);
+    while (wgs > 1 && (int)gridDim.x < 8 * (wgs - 1) + 1) wgs--;
+    const int bx = (int)blockIdx.x;
+    const bool is_seq = (bx % 8 == 0) && (bx / 8 < wgs);
 #if MRZ_HELPER_WGS > 0
-    if (blockIdx.x != 0) {
+    if (!is_seq) {
         mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
         return;
     }
+#else
+    if (!is_seq) return;
 #endif
+    const int j = bx / 8;
 
     mrz_cfg C;
     C.buf = a.buf;
@@ -63,216 +130,337 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     C.farm_hint = &farm_hint;
     int long_seen = 0;
     C.long_seen = &long_seen;
-    mrz_lead L;
-    L.p = st->p;
-    L.cur_p = st->cur_p;
-    L.cur_ofs = st->cur_ofs;
-    L.cur_len = st->cur_len;
-    L.last_match = st->last_match;
-    L.min_mask = st->min_mask;
-    L.tag_mask = st->tag_mask;
-    L.count = st->count;
-    L.clean_ptr = st->clean_ptr;
-    L.victim_round = st->victim_round;
-    L.n_events = st->n_events;
-    L.inserts = st->inserts;
-    L.tag_hits = st->tag_hits;
-    L.tag_misses = st->tag_misses;
-    L.last_len = 0;
-    L.mbytes = 0;
-
-    const int64_t hint_p0 = L.p, hint_ev0 = L.n_events;
     const int64_t seg_start = a.seg_start;
     const int64_t seg_end = a.seg_start + a.seg_len;
     const int64_t lim = (C.end < seg_end - 1) ? C.end : seg_end - 1;  // last candidate position of this launch
     const int64_t nwords = (a.seg_len + 63) / 64;
-
 #ifdef MRZ_SEQ_STATS
     int64_t stat[MRZ_ST_N];
     for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
 #else
     int64_t *stat = nullptr;
 #endif
-    if (tid == 0) S->cmd = 0;
-    __syncthreads();
 
-    if (wave != 0) {
-        // ---- waves 1..: wait for wave 0's commands; a wide batch is prepared by all waves together ------------
-        int seen = 0;
-        while (true) {
-            int c;
-            while ((c = mrz_uni(mrz_mb_load(&S->cmd))) == seen) __builtin_amdgcn_s_sleep(2);
-            seen = c;
-            if (mrz_uni(S->ctl[MRZ_CTL_MODE]) == 0) return;
-            const mrz_lead Lw = S->Lp;
-            mrz_wide_prep<MRZ_SEQ_WAVES>(C, Lw, S, a.tags, a.bitmap, seg_start, lim, nwords, mrz_uni(S->ctl[MRZ_CTL_WIDTH]),
-                                         tid, lane, wave, stat);
+    // ---- census: which sequencer workgroups share workgroup 0's XCD ----------------------------------------------
+    int n_act = 1, my = 0;
+    if (wgs > 1) {
+        if (tid == 0) {
+            G->xcc[j] = MRZ_XCC_ID();
+            __hip_atomic_fetch_add(&G->census, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-
-    // ---- wave 0: owns the matcher state, decides the mode, commits ------------------------------------------
-    int64_t win_base = -1;
-    mrz_u64 myword = 0;
-    bool ok = true;
-    int cmd_seq = 0;
-    int width = MRZ_W;         // batch width: small right after a match that swallowed the rest of a batch
-    int low_yield = 0;         // consecutive batches that committed <= 2 candidates
-    int seq_credit = 0;        // candidates to run through the cooperative path before batching again
-    // Right after an emission the next candidate often has long matches again (repetitive input): a batch
-    // would be formed, walked and probed only to stop at its first lane.  Four saturating counters, indexed by
-    // the classes (short / >= GREAT_MATCH) of the last two emitted matches, learn whether that is so; when it
-    // is, the first candidate after an emission goes straight through the cooperative path.
-    bool after_emit = false;
-    int emit_cls = 0;  // bit 0: last emitted match was great, bit 1: the one before
-    int pred_long[4] = { 0, 0, 0, 0 };
-    int stall = 0;  // iterations without any progress (cannot happen; keeps a logic error from hanging the GPU)
-    int64_t stall_p = L.p, stall_ev = L.n_events;
-
-    while (ok) {
-        int64_t pos = L.p + 1;
-        if (pos < seg_start) pos = seg_start;
-        if (pos > lim) break;
-        const bool first_after_emit = after_emit;
-        const int64_t ev_before = L.n_events;
-        long_seen = 0;
-        int mode = 1;
-        if (seq_credit > 0) {
-            seq_credit--;  // a stretch where every candidate has long matches: one at a time is cheaper
-            mode = 2;
-        } else if (first_after_emit && pred_long[emit_cls] >= 2)
-            mode = 2;
-#ifdef MRZ_NO_BATCH
-        mode = 2;
-#endif
-        int used = 0;
-        if (mode == 1) {
-            if (width <= 64) {
-                // a narrow batch (right after a match that swallowed the rest of the previous one): this wave alone,
-                // no workgroup barrier -- repetitive streams run on these
-                mrz_wide_prep<1>(C, L, S, a.tags, a.bitmap, seg_start, lim, nwords, width, lane, lane, 0, stat);
-            } else {
-                if (lane == 0) {
-                    S->Lp = L;
-                    S->ctl[MRZ_CTL_MODE] = 1;
-                    S->ctl[MRZ_CTL_WIDTH] = width;
-                }
-                cmd_seq++;
-                if (lane == 0) mrz_mb_store(&S->cmd, cmd_seq);
-                mrz_wide_prep<MRZ_SEQ_WAVES>(C, L, S, a.tags, a.bitmap, seg_start, lim, nwords, width, tid, lane, wave, stat);
-            }
-            mrz_wide_ret r;
-            mrz_wide_commit(C, L, S, lane, stat, &r);
-            used = r.used;
-            ok = r.ok;
-            if (r.long_seen) long_seen = 1;
-            // a match that swallowed the rest of the batch: the next batch starts small and regrows
-            if (r.skipped_out)
-                width = 64;
-            else if (width < MRZ_W)
-                width = width * 4 > MRZ_W ? MRZ_W : width * 4;
-            if (used <= 2 && r.coop_next) {
-                if (++low_yield >= MRZ_LOW_YIELD_RUNS) {
-                    seq_credit = MRZ_SEQ_CREDIT;
-                    low_yield = 0;
+    if (j == 0) {
+        if (tid == 0) {
+            int n = 1;
+            if (wgs > 1) {
+                long long spins = 0;  // the others start within microseconds; late ones are left out
+                while (__hip_atomic_load(&G->census, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)wgs &&
+                       spins++ < 2000)
+                    __builtin_amdgcn_s_sleep(4);
+                const int seen = (int)__hip_atomic_load(&G->census, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                G->active[0] = 0;
+                for (int k = 1; k < wgs; k++) {
+                    const bool okk = seen >= wgs && G->xcc[k] == G->xcc[0];
+                    G->active[k] = okk ? n : -1;
+                    if (okk) n++;
                 }
             } else
-                low_yield = 0;
-            if (r.coop_next && ok) mode = 2;
-        }
-        if (mode == 2 && ok) {
-            // ---- cooperative path: the first candidate after L.p (4096-position bitmap window) ---------------
-            PROF_T0();
-            pos = L.p + 1;
+                G->active[0] = 0;
+            // the matcher state, the first epoch
+            mrz_lead L;
+            L.p = st->p;
+            L.cur_p = st->cur_p;
+            L.cur_ofs = st->cur_ofs;
+            L.cur_len = st->cur_len;
+            L.last_match = st->last_match;
+            L.min_mask = st->min_mask;
+            L.tag_mask = st->tag_mask;
+            L.count = st->count;
+            L.clean_ptr = st->clean_ptr;
+            L.victim_round = st->victim_round;
+            L.n_events = st->n_events;
+            L.inserts = st->inserts;
+            L.tag_hits = st->tag_hits;
+            L.tag_misses = st->tag_misses;
+            L.last_len = 0;
+            L.mbytes = 0;
+            G->L = L;
+            G->gseq = 0;
+            G->gnw = 0;
+            G->farm_hint = 0;
+            int64_t pos = L.p + 1;
             if (pos < seg_start) pos = seg_start;
-            if (pos <= lim) {
-                const int64_t wb = seg_start + ((pos - seg_start) >> 12 << 12);
-                if (wb != win_base) {
-                    const int64_t idx = ((wb - seg_start) >> 6) + lane;
-                    myword = idx < nwords ? a.bitmap[idx] : 0ull;
-                    win_base = wb;
-                }
-                const int64_t lane_lo = wb + (int64_t)lane * 64;
-                mrz_u64 w = myword;
-                if (pos > lane_lo) {
-                    const int64_t sh = pos - lane_lo;
-                    w = sh >= 64 ? 0ull : (w >> sh) << sh;
-                }
-                if (lim < lane_lo + 63) {
-                    const int64_t keepbits = lim - lane_lo + 1;
-                    w = keepbits <= 0 ? 0ull : (w & mrz_low_mask((int)keepbits));
-                }
-                const mrz_u64 any = __ballot(w != 0ull);
-                if (!any) {
-                    const int64_t nxt = wb + 4096;  // nothing left in this window
-                    L.p = (nxt - 1 < lim) ? nxt - 1 : lim;
-                } else {
-                    ST_ADD(MRZ_ST_SEQ, 1);
-                    const int fl = __ffsll((long long)any) - 1;
-                    const mrz_u64 wl = (mrz_u64)mrz_bcast64((int64_t)w, fl);
-                    L.p = wb + (int64_t)fl * 64 + (__ffsll((long long)wl) - 1);
-                    const int64_t t = mrz_uni64(a.tags[L.p - seg_start]);
-                    if ((t & L.min_mask) == L.min_mask)  // src/rzip.c:573 with the mask reached by now
-                        ok = mrz_seq_candidate(C, L, &S->coop, t, lane, stat);
-                    used = 1;
-                }
-            }
-            PROF_ADD(MRZ_ST_T_SEQ);
+            G->epoch = 1;
+            G->base_word = (pos - seg_start) >> 6;
+            G->base_pos = pos;
+            G->base_batch = 0;
+            G->pw = mrz_words_per_batch(L.min_mask);
+            MRZ_RELEASE_AGENT();
+            __hip_atomic_store(&G->n_active, (unsigned long long)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (first_after_emit) {
-            const bool first_was_long = long_seen && used <= 1;
-            int &c = pred_long[emit_cls];
-            c = first_was_long ? (c < 3 ? c + 1 : 3) : (c > 0 ? c - 1 : 0);
-        }
-        if (L.p == stall_p && L.n_events == stall_ev) {
-            if (++stall > 64) {
-                if (lane == 0) st->error = 4;
-                ok = false;
-            }
-        } else {
-            stall = 0;
-            stall_p = L.p;
-            stall_ev = L.n_events;
-        }
-        after_emit = L.n_events != ev_before;
-        if (after_emit) emit_cls = ((emit_cls << 1) & 2) | (L.last_len >= MRZ_GREAT_MATCH ? 1 : 0);
     }
-    // send the other waves home
-    if (lane == 0) S->ctl[MRZ_CTL_MODE] = 0;
-    cmd_seq++;
-    if (lane == 0) mrz_mb_store(&S->cmd, cmd_seq);
+    if (tid == 0) {
+        long long spins = 0;
+        unsigned long long n = 0;
+        while ((n = __hip_atomic_load(&G->n_active, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0 && spins++ < (1ll << 22))
+            __builtin_amdgcn_s_sleep(4);
+        S->ctl[0] = (int)n;
+        S->ctl[1] = n ? G->active[j] : -1;
+    }
+    __syncthreads();
+    n_act = mrz_uni(S->ctl[0]);
+    my = mrz_uni(S->ctl[1]);
+    if (n_act <= 0 || my < 0) return;  // not taking part
+    const bool multi = n_act > 1;
+    const int64_t hint_p0 = G->L.p, hint_ev0 = G->L.n_events;
 
-    // release the helpers, then publish the state for the next segment's launch
+    mrz_lead L = G->L;  // (every wave keeps a copy; only the committing turn changes it)
+    unsigned long long b = (unsigned long long)my;
+    bool ok = true;
+    while (true) {
+        // ---- snapshot: token, epoch, masks (read as one: retried while a commit is writing them) ---------------
+        if (tid == 0) {
+            long long e = 0, bw = 0, bb = 0, mm = 0, tm = 0, bp = 0;
+            int pw = 1;
+            unsigned long long t0 = 0;
+            for (int tries = 0; tries < 64; tries++) {
+                t0 = __hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                e = __hip_atomic_load(&G->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bw = __hip_atomic_load(&G->base_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bb = __hip_atomic_load(&G->base_batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bp = __hip_atomic_load(&G->base_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pw = __hip_atomic_load(&G->pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mm = __hip_atomic_load(&G->L.min_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tm = __hip_atomic_load(&G->L.tag_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t1 = __hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (t1 == t0) break;
+            }
+            S->snap64[0] = (long long)t0;
+            S->snap64[1] = e;
+            S->snap64[2] = bw;
+            S->snap64[3] = bb;
+            S->snap64[4] = pw;
+            S->snap64[5] = mm;
+            S->snap64[6] = tm;
+            S->snap64[8] = bp;
+            S->snap64[7] = (long long)__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (multi) MRZ_ACQUIRE_AGENT();  // what earlier commits wrote is not served from this CU's L1
+        }
+        __syncthreads();
+        if (S->snap64[7]) break;
+        unsigned snap = (unsigned)S->snap64[0];
+        long long epoch = S->snap64[1];
+        long long base_word = S->snap64[2], base_batch = S->snap64[3];
+        int pw = (int)S->snap64[4];
+        long long p_min = S->snap64[5], p_tag = S->snap64[6], base_pos = S->snap64[8];
+        __syncthreads();
+        int64_t win_start = 0;
+        int win_len = 0;
+        PROF_T0();
+        bool have_prep = (long long)b >= base_batch;
+        if (have_prep) {
+            win_start = seg_start + (base_word + ((long long)b - base_batch) * pw) * 64;
+            win_len = pw * 64;
+            if (win_start <= lim)
+                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, a.tags, a.bitmap, seg_start, lim, nwords, win_start, win_len, base_pos, p_min,
+                                             p_tag, tid, lane, wave, stat);
+        }
+
+        PROF_ADD(MRZ_ST_T_PREP);
+        // ---- wait for this batch's turn ------------------------------------------------------------------------
+        if (tid == 0) {
+            long long spins = 0;
+            int verdict = 1;
+            while (true) {
+                const unsigned long long tk = __hip_atomic_load(&G->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == b) break;
+                if (__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    verdict = 0;
+                    break;
+                }
+                if (spins++ > MRZ_TURN_SPIN_LIMIT) {  // cannot happen: every turn ends in a token or in quit
+                    verdict = -1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (verdict > 0) (void)__hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (verdict > 0 && multi) MRZ_ACQUIRE_AGENT();
+            S->ctl[2] = verdict;
+        }
+        __syncthreads();
+        const int verdict = mrz_uni(S->ctl[2]);
+        PROF_ADD(MRZ_ST_T_TURN);
+        if (verdict == 0) break;
+        if (verdict < 0) {
+            if (tid == 0) {
+                st->error = 5;
+                __hip_atomic_store(&G->quit, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
+        // ---- this workgroup's turn: the matcher state is ours ----------------------------------------------------
+        L = G->L;
+        gseq = G->gseq;
+        gnw = G->gnw;
+        farm_hint = G->farm_hint;
+        const long long cur_epoch = G->epoch;
+        if (cur_epoch != epoch || !have_prep || L.min_mask != p_min || L.tag_mask != p_tag) {
+            // prepared under an older epoch (or not at all): once more, now that everything before it is committed
+            epoch = cur_epoch;
+            base_word = G->base_word;
+            base_batch = G->base_batch;
+            base_pos = G->base_pos;
+            pw = G->pw;
+            snap = (unsigned)b;
+            win_start = seg_start + (base_word + ((long long)b - base_batch) * pw) * 64;
+            win_len = pw * 64;
+            __syncthreads();
+            if (win_start <= lim)
+                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, a.tags, a.bitmap, seg_start, lim, nwords, win_start, win_len, base_pos,
+                                             L.min_mask, L.tag_mask, tid, lane, wave, stat);
+        }
+        bool finish = false;
+        if (win_start > lim) {
+            // the segment is done: nothing but the end is left
+            if (L.p < lim) L.p = lim;
+            finish = true;
+        } else {
+            // commit; a batch that ends before its window does (a hand-over that cut it short, a back-jump, more
+            // candidates than lanes, the cull window used up) goes on inside the window -- the rest is prepared again
+            // from the matcher's position, the windows of the batches behind it stay what they are
+            for (int rounds = 0;; rounds++) {
+                PROF_T0R();
+                mrz_wide_precommit<MRZ_SEQ_WAVES>(C, L, S, wlog, snap, (unsigned)b, tid, lane, wave, stat);
+                PROF_ADD(MRZ_ST_T_PRECOMMIT);
+                if (wave == 0) {
+                    mrz_wide_ret r;
+                    r.used = 0;
+                    r.ok = true;
+                    r.whole = true;
+                    r.stop_batch = false;
+                    mrz_wide_commit(C, L, S, wlog, (unsigned)b, lane, stat, &r);
+                    const int64_t w_end = mrz_uni64(S->w_end), adv_to = mrz_uni64(S->adv_to);
+                    const int total = mrz_uni(S->total);
+                    const bool masks_moved = L.min_mask != mrz_uni64(S->prep_min_mask) || L.tag_mask != mrz_uni64(S->prep_tag_mask);
+                    const bool all_lanes = r.whole && !r.stop_batch;
+                    if (all_lanes && adv_to > L.p) L.p = adv_to;  // no candidate is left up to there
+                    const bool window_done = all_lanes && adv_to == w_end;
+                    const bool far = L.p > w_end + (int64_t)n_act * win_len;
+                    // the window size follows what the windows turn out to hold (the bitmap's density is not the mask's)
+                    int new_pw = 0;
+                    if (rounds == 0 && all_lanes) {
+                        if (!window_done)
+                            new_pw = total > MRZ_W ? pw * 3 / 4 : pw / 2;  // too many: candidates, or bits to examine
+                        else if (total < MRZ_W * 3 / 8 && pw < MRZ_W) {
+                            const int small = mrz_uni(G->small_run) + 1;
+                            if (lane == 0) G->small_run = small >= 4 ? 0 : small;
+                            if (small >= 4) new_pw = (int)((long long)pw * (MRZ_W * 3 / 4) / (total > 16 ? total : 16));
+                        } else if (lane == 0)
+                            G->small_run = 0;
+                        if (new_pw > MRZ_W) new_pw = MRZ_W;
+                        if (new_pw < 1 && new_pw != 0) new_pw = 1;
+                        if (new_pw == pw) new_pw = 0;
+                    }
+                    int verdict2 = 0;  // 0: pass the token on; 1: go on inside this window; 2: new epoch
+                    if (!r.ok || rounds > 2 * MRZ_W)
+                        verdict2 = 0;
+                    else if (masks_moved || far || L.p + 1 < win_start || new_pw > 0)
+                        verdict2 = 2;
+                    else if (window_done || L.p >= w_end)
+                        verdict2 = 0;
+                    else
+                        verdict2 = 1;
+                    if (L.p >= lim) {
+                        finish = true;
+                        if (verdict2 == 1) verdict2 = 0;
+                    }
+                    ST_ADD(MRZ_ST_E_MORE, (all_lanes && !window_done) ? 1 : 0);
+                    ST_ADD(MRZ_ST_RESET, verdict2 == 2 ? 1 : 0);
+                    ST_ADD(MRZ_ST_REPREP, verdict2 == 1 ? 1 : 0);
+                    if (lane == 0) {
+                        if (verdict2 == 2) {
+                            int64_t pos = L.p + 1;
+                            if (pos < seg_start) pos = seg_start;
+                            G->epoch = cur_epoch + 1;
+                            G->base_word = (pos - seg_start) >> 6;
+                            G->base_pos = pos;
+                            G->base_batch = (long long)b + 1;
+                            G->pw = masks_moved ? mrz_words_per_batch(L.min_mask) : (new_pw > 0 ? new_pw : pw);
+                        }
+                        S->ctl[3] = ((r.ok && rounds <= 2 * MRZ_W) ? 0 : 1) | (finish ? 2 : 0) | (verdict2 == 1 ? 4 : 0);
+                        S->lead = L;
+                    }
+                }
+                __syncthreads();
+                const int fl = mrz_uni(S->ctl[3]);
+                if (fl & 1) ok = false;
+                finish = (fl & 2) != 0;
+                if (!(fl & 4)) break;
+                if (wave != 0) L = S->lead;
+                snap = (unsigned)b;
+                __syncthreads();
+                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, a.tags, a.bitmap, seg_start, lim, nwords, win_start, win_len, L.p + 1,
+                                             L.min_mask, L.tag_mask, tid, lane, wave, stat);
+            }
+        }
+        // ---- hand the state on -----------------------------------------------------------------------------------
+        if (wave == 0 && lane == 0) {
+            G->L = L;
+            G->gseq = gseq;
+            G->gnw = gnw;
+            G->farm_hint = farm_hint;
+        }
+        __syncthreads();  // every wave's table / log stores are complete (the barrier waits for them)
+        if (!ok || finish) {
+            if (tid == 0) {
+                // the end of the launch: publish the state for the next segment's launch, release everybody
+                st->p = L.p;
+                st->cur_p = L.cur_p;
+                st->cur_ofs = L.cur_ofs;
+                st->cur_len = L.cur_len;
+                st->last_match = L.last_match;
+                st->min_mask = L.min_mask;
+                st->tag_mask = L.tag_mask;
+                st->count = L.count;
+                st->clean_ptr = L.clean_ptr;
+                st->victim_round = L.victim_round;
+                st->n_events = L.n_events;
+                st->inserts = L.inserts;
+                st->tag_hits = L.tag_hits;
+                st->tag_misses = L.tag_misses;
+                st->finished = L.p >= C.end ? 1 : 0;
+                st->hint_positions = L.p - hint_p0;
+                st->hint_events = L.n_events - hint_ev0;
+                st->hint_matched = L.mbytes;
+                MRZ_RELEASE_AGENT();
+                __hip_atomic_store(&G->quit, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #if MRZ_HELPER_WGS > 0
-    if (lane == 0 && C.gmb) mrz_g_storeu(&C.gmb->quit, 1ull);
+                if (C.gmb) mrz_g_storeu(&C.gmb->quit, 1ull);
 #endif
-    if (lane == 0) {
-        st->p = L.p;
-        st->cur_p = L.cur_p;
-        st->cur_ofs = L.cur_ofs;
-        st->cur_len = L.cur_len;
-        st->last_match = L.last_match;
-        st->min_mask = L.min_mask;
-        st->tag_mask = L.tag_mask;
-        st->count = L.count;
-        st->clean_ptr = L.clean_ptr;
-        st->victim_round = L.victim_round;
-        st->n_events = L.n_events;
-        st->inserts = L.inserts;
-        st->tag_hits = L.tag_hits;
-        st->tag_misses = L.tag_misses;
-        st->finished = L.p >= C.end ? 1 : 0;
-        st->hint_positions = L.p - hint_p0;
-        st->hint_events = L.n_events - hint_ev0;
-        st->hint_matched = L.mbytes;
-#ifdef MRZ_SEQ_STATS
-        for (int k = 0; k < MRZ_ST_N; k++) st->prof[k] += stat[k];
-#endif
+            }
+            break;
+        }
+        if (tid == 0) {
+            if (multi) MRZ_RELEASE_AGENT();
+            __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        b += (unsigned long long)n_act;
+        __syncthreads();
     }
+#ifdef MRZ_SEQ_STATS
+    if (tid == 0)
+        for (int k = 0; k < MRZ_ST_N; k++)
+            if (stat[k]) __hip_atomic_fetch_add((unsigned long long *)&st->prof[k], (unsigned long long)stat[k], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
+extern "C" size_t mrz_sequencer_wlog_size(int64_t nslots);
 extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
                                            const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
-                                           int64_t seg_start, int64_t seg_len, void *gmailbox, int n_helpers) {
+                                           int64_t seg_start, int64_t seg_len, void *gmailbox, int n_helpers,
+                                           void *wide_shared, unsigned *wlog, int64_t nslots, int seq_wgs) {
     mrz_seq_args a;
     a.buf = buf;
     a.tab = tab;
@@ -289,13 +477,26 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     if (n_helpers > MRZ_HELPER_WGS) n_helpers = MRZ_HELPER_WGS;
     if (n_helpers < 0 || !gmailbox) n_helpers = 0;
     a.n_helpers = n_helpers;
-    if (gmailbox) {
-        hipError_t e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(1 + a.n_helpers), dim3(MRZ_SEQ_THREADS), 0, stream, a);
+    if (seq_wgs < 1) seq_wgs = 1;
+    if (seq_wgs > MRZ_SEQ_WGS) seq_wgs = MRZ_SEQ_WGS;
+    hipError_t e = hipSuccess;
+    if (gmailbox) e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(wide_shared, 0, sizeof(mrz_wide_shared), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(wlog, 0, (size_t)mrz_sequencer_wlog_size(nslots), stream);
+    if (e != hipSuccess) return e;
+    // blocks 0, 8, 16, ... are the sequencer workgroups (one XCD), the rest helpers: enough blocks for both
+    unsigned grid = (unsigned)(seq_wgs + a.n_helpers);
+    if (grid < (unsigned)(8 * (seq_wgs - 1) + 1)) grid = (unsigned)(8 * (seq_wgs - 1) + 1);
+#ifdef MRZ_EMU_LDS_PER_BLOCK
+    emu::request_coresident();  // (test emulator: this kernel's workgroups wait for each other)
+#endif
+    hipLaunchKernelGGL(mrz_sequencer_kernel, dim3(grid), dim3(MRZ_SEQ_THREADS), 0, stream, a, (mrz_wide_shared *)wide_shared,
+                       wlog, seq_wgs);
     return hipGetLastError();
 }
+
+extern "C" size_t mrz_sequencer_shared_size(void) { return sizeof(mrz_wide_shared); }
+extern "C" size_t mrz_sequencer_wlog_size(int64_t nslots) { return (size_t)((nslots >> MRZ_WLOG_SHIFT) + 1) * sizeof(unsigned); }
 
 // helper workgroups a launch on `device` should carry by default: about one per CU, leaving the leader's CU and a
 // few for co-resident kernels free (MRZ_FARM_WGS overrides)

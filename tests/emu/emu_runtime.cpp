@@ -38,11 +38,15 @@ struct Fiber {
 Fiber *cur = nullptr;
 Idx cur_tid, cur_bid, cur_bdim, cur_gdim;
 static ucontext_t sched_ctx;
-static BlockSync blk;
+static BlockSync blk_single;
+static BlockSync *blkp = &blk_single;  // the running workgroup's barrier state
 static const std::function<void()> *cur_body;
 static const size_t STACK = 256 * 1024;
 
+static unsigned long long n_waits = 0, n_yields = 0;
+static struct Report { ~Report() { if (getenv("MRZ_EMU_COUNT")) fprintf(stderr, "emu: %llu waits, %llu yields\n", n_waits, n_yields); } } report;
 static void yield_wait(const uint64_t *ptr, uint64_t val) {
+    n_waits++;
     Fiber *me = cur;
     me->wait_ptr = ptr;
     me->wait_val = val;
@@ -86,6 +90,7 @@ int shfl_xor(int v, int mask) {
 
 // a spin-wait's sleep: let the other fibers run
 void yield() {
+    n_yields++;
     Fiber *me = cur;
     me->wait_ptr = nullptr;
     swapcontext(&me->ctx, &sched_ctx);
@@ -94,12 +99,12 @@ void yield() {
 int first_live_lane() { return __builtin_ffsll((long long)cur->wave->live_mask) - 1; }
 
 void syncthreads() {
-    if (++blk.arrived >= blk.alive) {
-        blk.arrived = 0;
-        blk.phase++;
+    if (++blkp->arrived >= blkp->alive) {
+        blkp->arrived = 0;
+        blkp->phase++;
     } else {
-        const uint64_t ph = blk.phase;
-        yield_wait(&blk.phase, ph);
+        const uint64_t ph = blkp->phase;
+        yield_wait(&blkp->phase, ph);
     }
 }
 
@@ -112,12 +117,107 @@ static void fiber_main() {
     w->alive--;
     w->live_mask &= ~(1ull << me->lane);
     if (w->alive > 0 && w->arrived >= w->alive) w->complete();
-    blk.alive--;
-    if (blk.alive > 0 && blk.arrived >= blk.alive) {
-        blk.arrived = 0;
-        blk.phase++;
+    blkp->alive--;
+    if (blkp->alive > 0 && blkp->arrived >= blkp->alive) {
+        blkp->arrived = 0;
+        blkp->phase++;
     }
     swapcontext(&me->ctx, &sched_ctx);
+}
+
+// ---- co-resident mode ----------------------------------------------------------------------------------------------
+// MRZ_EMU_CORESIDENT=1 in the environment: the workgroups of a (small) grid run interleaved instead of one after
+// another, so that kernels whose workgroups wait for each other (the sequencer's token) can be executed.  Still one
+// OS thread: a workgroup runs until every one of its fibers is waiting or has yielded, then the next one does.
+// `__shared__` is a function-local static here, i.e. ONE copy for all workgroups: a kernel that is to run in this mode
+// indexes its LDS by workgroup under MRZ_EMU_LDS_PER_BLOCK.
+struct BlockCtx {
+    Idx bid;
+    BlockSync blk;
+    std::vector<WaveSync> waves;
+    std::vector<Fiber> fibers;
+    unsigned remaining = 0;
+};
+
+static bool coresident_requested = false;
+void request_coresident() { coresident_requested = true; }  // the next launch is of a kernel written for it
+
+static void launch_coresident(dim3 grid, dim3 block, const std::function<void()> &body) {
+    const unsigned nthreads = block.x * block.y * block.z;
+    const unsigned nwaves = (nthreads + 63) / 64;
+    const unsigned nblocks = grid.x * grid.y * grid.z;
+    static std::vector<BlockCtx *> pool;
+    while (pool.size() < nblocks) pool.push_back(new BlockCtx());
+    cur_body = &body;
+    cur_bdim = { block.x, block.y, block.z };
+    cur_gdim = { grid.x, grid.y, grid.z };
+    for (unsigned b = 0; b < nblocks; b++) {
+        BlockCtx &B = *pool[b];
+        B.bid = { b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y) };
+        B.blk = BlockSync();
+        B.blk.alive = (int)nthreads;
+        if (B.fibers.size() < nthreads) {
+            size_t old = B.fibers.size();
+            B.fibers.resize(nthreads);
+            for (size_t i = old; i < nthreads; i++) B.fibers[i].stack = (char *)malloc(STACK);
+        }
+        if (B.waves.size() < nwaves) B.waves.resize(nwaves);
+        for (unsigned wv = 0; wv < nwaves; wv++) {
+            B.waves[wv] = WaveSync();
+            unsigned lanes = nthreads - wv * 64;
+            B.waves[wv].alive = lanes > 64 ? 64 : (int)lanes;
+            B.waves[wv].live_mask = B.waves[wv].alive == 64 ? ~0ull : ((1ull << B.waves[wv].alive) - 1);
+            memset(B.waves[wv].slot, 0, sizeof(B.waves[wv].slot));
+        }
+        for (unsigned t = 0; t < nthreads; t++) {
+            Fiber &f = B.fibers[t];
+            f.tid = { t % block.x, (t / block.x) % block.y, t / (block.x * block.y) };
+            f.lane = (int)(t & 63);
+            f.wave = &B.waves[t / 64];
+            f.done = false;
+            f.wait_ptr = nullptr;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack;
+            f.ctx.uc_stack.ss_size = STACK;
+            f.ctx.uc_link = &sched_ctx;
+            makecontext(&f.ctx, fiber_main, 0);
+        }
+        B.remaining = nthreads;
+    }
+    unsigned live_blocks = nblocks;
+    unsigned long long idle_rounds = 0;
+    while (live_blocks) {
+        bool any = false;
+        for (unsigned b = 0; b < nblocks; b++) {
+            BlockCtx &B = *pool[b];
+            if (!B.remaining) continue;
+            // a few passes over this workgroup, then the next one gets the processor
+            for (int pass = 0; pass < 4 && B.remaining; pass++) {
+                bool progressed = false;
+                for (unsigned t = 0; t < nthreads; t++) {
+                    Fiber &f = B.fibers[t];
+                    if (f.done) continue;
+                    if (f.wait_ptr && *f.wait_ptr == f.wait_val) continue;
+                    f.wait_ptr = nullptr;
+                    cur = &f;
+                    cur_tid = f.tid;
+                    cur_bid = B.bid;
+                    blkp = &B.blk;
+                    swapcontext(&sched_ctx, &f.ctx);
+                    progressed = true;
+                    if (f.done) B.remaining--;
+                }
+                if (!progressed) break;
+                any = true;
+            }
+            if (!B.remaining) live_blocks--;
+        }
+        if (!any && ++idle_rounds > 4) {
+            fprintf(stderr, "emu: deadlock in co-resident grid\n");
+            abort();
+        }
+    }
+    cur = nullptr;
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
@@ -125,6 +225,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     // consumer runs the LZ4 gate while the producer sequences) may launch concurrently
     static std::mutex launch_mu;
     std::lock_guard<std::mutex> launch_lock(launch_mu);
+    const bool asked = coresident_requested;
+    coresident_requested = false;
+    {
+        const char *e = getenv("MRZ_EMU_CORESIDENT");
+        if (asked && e && *e == '1' && grid.x * grid.y * grid.z > 1 && grid.x * grid.y * grid.z <= 64) {
+            launch_coresident(grid, block, body);
+            return;
+        }
+    }
     const unsigned nthreads = block.x * block.y * block.z;
     const unsigned nwaves = (nthreads + 63) / 64;
     static std::vector<Fiber> fibers;
@@ -142,8 +251,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++) {
                 cur_bid = { bx, by, bz };
-                blk = BlockSync();
-                blk.alive = (int)nthreads;
+                blkp = &blk_single;
+                blk_single = BlockSync();
+                blk_single.alive = (int)nthreads;
                 for (unsigned wv = 0; wv < nwaves; wv++) {
                     waves[wv] = WaveSync();
                     unsigned lanes = nthreads - wv * 64;

@@ -53,6 +53,7 @@ int shfl_xor(int v, int mask);
 void syncthreads();
 int first_live_lane();
 void yield();
+void request_coresident();
 }  // namespace emu
 
 #define threadIdx (emu::cur_tid)
