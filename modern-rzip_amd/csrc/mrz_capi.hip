@@ -186,7 +186,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         if (hipMalloc(&ctx->d_seq_shared, mrz_sequencer_shared_size()) != hipSuccess ||
             hipMalloc((void **)&ctx->d_wlog, mrz_sequencer_wlog_size(ctx->nslots)) != hipSuccess)
             rc = MRZ_E_NOMEM;
-        ctx->seq_wgs = 4;
+        ctx->seq_wgs = 3;
         if (const char *e = getenv("MRZ_SEQ_WGS")) ctx->seq_wgs = atoi(e);
     }
     if (!rc && max_chunk > 0) {

@@ -47,7 +47,7 @@ struct mrz_ctx {
     void *d_gmailbox;  // mailbox of the sequencer's helper workgroups
     void *d_seq_shared;  // what the wide engine's sequencer workgroups hand to each other (token, matcher state)
     unsigned *d_wlog;    // its write log: one batch stamp per few table slots
-    int seq_wgs;         // sequencer workgroups per wide launch (MRZ_SEQ_WGS in the environment; default 4)
+    int seq_wgs;         // sequencer workgroups per wide launch (MRZ_SEQ_WGS in the environment; default 3)
     int farm_helpers;  // helper workgroups per sequencer launch; -1 = farm_default
     int farm_default;  // the default for this ctx's device (about one per CU), fixed in mrz_open
     void *d_rs_tables;  // Reed-Solomon tables (mrz_rs.hip)

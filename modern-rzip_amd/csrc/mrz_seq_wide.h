@@ -39,6 +39,7 @@
 #define MRZ_PAIR_MAX (MRZ_POOL * 4)
 #define MRZ_BH_SIZE 2048              // block-hash entries (64-slot blocks written by this batch)
 #define MRZ_BH_WRITERS 5
+#define MRZ_OV_ROUNDS 3               // overlay rounds of a preparation (a repaired writer makes its readers repairable)
 #define MRZ_CW_WORDS 32               // cull window: 32 x 64 slots ahead of tag_clean_ptr
 #define MRZ_NW_MAX 192
 #define MRZ_XW_MAX 48
@@ -955,13 +956,37 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     // ---- B3: overlay walk.  A stale lane whose (one or two) earlier writers are themselves sound walks once more
     // with those lanes' writes laid over the table -- what it would read had they been committed.  The common case
     // is the next position carrying the same tag (the XOR tag only sees the multiset of the 31 bytes).
-    {
+    int cwhy = 0;  // why a stale lane could not be repaired here (0 = not tried yet; diagnostics, and who tries again)
+    // Rounds: a lane whose writer was itself stale can be repaired once that writer has been (its repaired writes are
+    // published and listed in nw_*), so the phase is run up to MRZ_OV_ROUNDS times, until no lane is eligible.
+    for (int round = 0; round < MRZ_OV_ROUNDS; round++) {
+        if (round > 0 && act && !cplx && conf && (cwhy == 3 || cwhy == 4 || cwhy == 7)) {
+            // who writes into what this lane has read, as things stand now: the block hash (whose lanes' published
+            // writes are up to date) and the repaired lanes' new writes
+            for (int k = 0; k < MRZ_WR_MAX; k++) wr[k] = -1;
+            nwr = mrz_bh_readers(S, tid, h, len1, wl.h2, wl.len2, smask, wr);
+            int nw0 = S->nw_cnt;
+            if (nw0 > MRZ_NW_MAX) nw0 = MRZ_NW_MAX;
+            for (int k = 0; k < nw0 && nwr >= 0; k++) {
+                const int wlane = S->nw_lane[k];
+                if (wlane >= tid) continue;
+                const int sl = S->nw_slot[k];
+                if (!((len1 > 0 && mrz_in_range(sl, h, len1, smask)) || (wl.len2 > 0 && mrz_in_range(sl, wl.h2, wl.len2, smask))))
+                    continue;
+                bool dup = false;
+                for (int z = 0; z < nwr && z < MRZ_WR_MAX; z++) dup = dup || wr[z] == wlane;
+                if (!dup) {
+                    if (nwr < MRZ_WR_MAX) wr[nwr] = wlane;
+                    nwr++;
+                }
+            }
+            cwhy = 0;
+        }
         const bool win_stale = act && !cplx && conf && nwr == 0;  // stale only because of the cull window
         S->lf[tid] = (unsigned char)((conf ? 1 : 0) | (cplx ? 2 : 0) | (act ? 4 : 0));
         mrz_prep_sync<NW>();
-        bool elig = act && !cplx && conf && !win_stale && nwr >= 1 && nwr <= MRZ_WR_MAX;
-        int cwhy = 0;  // why a stale lane could not be repaired here (diagnostics)
-        if (act && !cplx && conf && !elig) cwhy = win_stale ? 1 : 4;
+        bool elig = act && !cplx && conf && !win_stale && nwr >= 1 && nwr <= MRZ_WR_MAX && cwhy == 0;
+        if (act && !cplx && conf && !elig && cwhy == 0) cwhy = win_stale ? 1 : 4;
         mrz_ov ov;
         ov.n = 0;
         int ov_src[MRZ_OV_MAX];  // writer lane * 2 + (0: its insert slot, 1: its occupant's new slot)
@@ -1024,7 +1049,8 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
         const mrz_u64 m_el = __ballot(elig);
         int n_el;
         (void)mrz_wide_incl<NW>(lane == 0 ? __popcll(m_el) : 0, S->wt5, lane, wave, &n_el);
-        if (n_el) {  // uniform
+        if (!n_el) break;  // uniform
+        {
             ST_ADD(MRZ_ST_OVL, n_el);
             mrz_wl wn;
             mrz_wide_walk<true>(C, S, elig, tid, lane, t, ins, better, ov, wn);
@@ -1115,7 +1141,7 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
             if (act && !cplx && !conf) {
                 for (int k = 0; k < nw; k++) {
                     const int wlane = S->nw_lane[k];
-                    if (wlane >= tid) continue;
+                    if (wlane >= tid || wlane == dep0 || wlane == dep1 || wlane == dep2) continue;
                     const int sl = S->nw_slot[k];
                     if ((len1 > 0 && mrz_in_range(sl, h, len1, smask)) || (wl.len2 > 0 && mrz_in_range(sl, wl.h2, wl.len2, smask))) {
                         conf = true;
@@ -1132,14 +1158,14 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
             }
 #endif
         }
-        ST_COUNT(MRZ_ST_C_WIN, conf && cwhy == 1);
-        ST_COUNT(MRZ_ST_C_EVICT, conf && cwhy == 2);
-        ST_COUNT(MRZ_ST_C_DEEP, conf && cwhy == 3);
-        ST_COUNT(MRZ_ST_C_MANY, conf && cwhy == 4);
-        ST_COUNT(MRZ_ST_C_FAIL, conf && cwhy == 5);
-        ST_COUNT(MRZ_ST_C_TIE, conf && cwhy == 6);
-        ST_COUNT(MRZ_ST_C_NW, conf && cwhy == 7);
     }
+    ST_COUNT(MRZ_ST_C_WIN, conf && cwhy == 1);
+    ST_COUNT(MRZ_ST_C_EVICT, conf && cwhy == 2);
+    ST_COUNT(MRZ_ST_C_DEEP, conf && cwhy == 3);
+    ST_COUNT(MRZ_ST_C_MANY, conf && cwhy == 4);
+    ST_COUNT(MRZ_ST_C_FAIL, conf && cwhy == 5);
+    ST_COUNT(MRZ_ST_C_TIE, conf && cwhy == 6);
+    ST_COUNT(MRZ_ST_C_NW, conf && cwhy == 7);
     PROF_ADD(MRZ_ST_T_OVL);
 
     // ---- C: pairs (lanes whose walk stands) ----------------------------------------------------------------

@@ -63,7 +63,9 @@ struct mrz_wide_shared {          // device memory, zeroed by the host before ev
 #define MRZ_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define MRZ_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define MRZ_XCC_ID() (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15)
+#define MRZ_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
+#define MRZ_WAIT_STORES() ((void)0)
 #define MRZ_ACQUIRE_AGENT() ((void)0)
 #define MRZ_RELEASE_AGENT() ((void)0)
 #define MRZ_XCC_ID() 0
@@ -268,7 +270,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 
         PROF_ADD(MRZ_ST_T_PREP);
         // ---- wait for this batch's turn ------------------------------------------------------------------------
+        // The sequencer workgroups share one XCD (the census), so its L2 is where they meet: what has to happen on this
+        // side is that no line of this CU's L1 outlives the hand-over.  Nothing is loaded through the L1 between here and
+        // the token (the poll is an agent-scope load, which bypasses it; the other waves sit at the barrier), so the
+        // invalidate is issued now and completes while the token is awaited.
         if (tid == 0) {
+            if (multi) MRZ_ACQUIRE_AGENT();
             long long spins = 0;
             int verdict = 1;
             while (true) {
@@ -284,8 +291,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (verdict > 0) (void)__hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (verdict > 0 && multi) MRZ_ACQUIRE_AGENT();
+            MRZ_WAIT_STORES();  // (the invalidate has completed)
             S->ctl[2] = verdict;
         }
         __syncthreads();
@@ -411,7 +417,8 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             G->gnw = gnw;
             G->farm_hint = farm_hint;
         }
-        __syncthreads();  // every wave's table / log stores are complete (the barrier waits for them)
+        MRZ_WAIT_STORES();  // every wave's table / log stores have reached the L2 ...
+        __syncthreads();    // ... before the lane that passes the token on leaves this barrier
         if (!ok || finish) {
             if (tid == 0) {
                 // the end of the launch: publish the state for the next segment's launch, release everybody
@@ -442,8 +449,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             break;
         }
         if (tid == 0) {
-            if (multi) MRZ_RELEASE_AGENT();
-            __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // every wave's stores have reached the L2 (each waited for its own before the barrier above; this lane's
+            // state stores are waited for here); the XCD's L2 need not be written back for a reader on the same XCD
+            MRZ_WAIT_STORES();
+            __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         b += (unsigned long long)n_act;
         __syncthreads();

@@ -70,6 +70,21 @@ def test_batch_engine_culling_and_mask_promotion(emu_lib, oracle):
     _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 20, seed=4), level=1, table=True)
 
 
+@pytest.mark.parametrize("wgs", [2, 3])
+def test_sequencer_workgroups_take_turns(emu_lib, oracle, wgs, monkeypatch):
+    """Several sequencer workgroups (the emulator runs them interleaved): batches prepared ahead are re-validated
+    against the write log at their turn -- stale lanes, lanes dropped by a match emitted meanwhile, new epochs after
+    a mask promotion and continuation inside a window all occur on these inputs; results stay the reference's."""
+    monkeypatch.setenv("MRZ_EMU_CORESIDENT", "1")
+    monkeypatch.setenv("MRZ_SEQ_WGS", str(wgs))
+    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(160000, seed=4), table=True)
+    _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(100000, seed=3), table=True)
+    _parity.check_chunk(emu_lib, oracle, _util.rep64k(24, seed=9, period=2048), victim_round=3)
+    blk = _util.xorshift_noise(70000, seed=12)
+    _parity.check_chunk(emu_lib, oracle, blk + blk)
+    _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 19, seed=4), level=1, table=True)
+
+
 def test_crc32_kernel(emu_lib):
     with m.RzipContext(lib=emu_lib) as ctx:
         for n in (0, 1, 15, 16, 17, 1000, 65535, 65536, 65537, 3 * 65536 + 77):
