@@ -621,7 +621,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                          "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw", "t_ovl",
                                          "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit", "reprep", "w_stale", "w_drop", "reset",
                                          "t_turn", "t_prep", "t_precommit", "e_mask", "e_cull", "e_xw", "e_inwin", "e_window", "e_bulk",
-                                         "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk" };
+                                         "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk", "t_turnwork", "t_snap", "rebulk" };
         for (int k = 0; k < 96; k++) if (names[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;

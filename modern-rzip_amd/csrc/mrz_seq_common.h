@@ -70,7 +70,7 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        MRZ_ST_C_MANY, MRZ_ST_C_FAIL, MRZ_ST_C_TIE, MRZ_ST_C_NW, MRZ_ST_T_OVL, MRZ_ST_H_PRE, MRZ_ST_H_CAND, MRZ_ST_H_POST,
        MRZ_ST_T_SCAN, MRZ_ST_T_FOLD, MRZ_ST_T_COMMIT, MRZ_ST_REPREP, MRZ_ST_W_STALE, MRZ_ST_W_DROP, MRZ_ST_RESET,
        MRZ_ST_T_TURN, MRZ_ST_T_PREP, MRZ_ST_T_PRECOMMIT, MRZ_ST_E_MASK, MRZ_ST_E_CULL, MRZ_ST_E_XW, MRZ_ST_E_INWIN,
-       MRZ_ST_E_WINDOW, MRZ_ST_E_BULK, MRZ_ST_E_MORE, MRZ_ST_T_PC_CW, MRZ_ST_T_PC_LOG, MRZ_ST_T_PC_BEST, MRZ_ST_T_PC_BULK,
+       MRZ_ST_E_WINDOW, MRZ_ST_E_BULK, MRZ_ST_E_MORE, MRZ_ST_T_PC_CW, MRZ_ST_T_PC_LOG, MRZ_ST_T_PC_BEST, MRZ_ST_T_PC_BULK, MRZ_ST_T_TURNWORK, MRZ_ST_T_SNAP, MRZ_ST_REBULK,
        MRZ_ST_N };
 
 struct mrz_seq_args {

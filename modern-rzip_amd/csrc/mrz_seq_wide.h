@@ -62,7 +62,8 @@ struct mrz_wide_lds {
     int cmd;              // bumped by wave 0 for every command; the other waves wait on it
     int nb, total;        // lanes of the prepared batch; candidates in its bitmap window
     int bulk_y, bulk_a1, bulk_a2, bulk_end;  // bulk commit done by the pre-commit step: lanes [first_live, bulk_y), totals
-    int first_live;       // first lane behind L.p
+    int first_live;       // first lane behind L.p (where the commit starts or resumes)
+    int rank0;            // culls of this batch's cull window used up before that lane
     long long snap64[10];
     mrz_lead lead;        // the matcher's state after a commit, for the waves that did not run it  // the snapshot a preparation works from (token, epoch, window base, masks)
     int64_t prep_min_mask, prep_tag_mask;  // the masks the batch was prepared under
@@ -755,6 +756,7 @@ struct mrz_wide_ret {
     bool ok;           // false: event list overflow
     bool whole;        // every lane of the batch has been dealt with (committed, dropped or handed over)
     bool stop_batch;   // the masks have moved / the cull window no longer holds: batches prepared ahead are void
+    bool rebulk;       // a long clean stretch lies ahead (from S->first_live, cull rank S->rank0): bulk-commit it, come back
 };
 
 // lane flags published for the committing wave
@@ -1218,6 +1220,146 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     mrz_prep_sync<NW>();
 }
 
+// BULK COMMIT (E0): the lanes from `s_from` up to the first one that is stale, complex or has a match to fold need none
+// of the lazy-match logic (no match can be adopted or emitted among them when none is pending): all waves commit them
+// at once -- scans for victim_round, hash_count and the cull ranks (from rank `rank0` of the cull window on) as in the
+// commit proper -- and leave wave 0 the totals in S->bulk_*.  Match-free stretches (noise) are committed entirely here:
+// by the pre-commit step for the head of the batch, and again whenever the commit finds a long clean stretch behind a
+// hand-over (`late`: the staleness rules of the commit -- writers that did not commit as prepared, hand-over writes --
+// are applied first).  All threads; ends in a barrier.
+template <int NW>
+__device__ static __attribute__((noinline)) void mrz_wide_bulk(const mrz_cfg &C, const mrz_lead &L, mrz_wide_lds *S, unsigned *__restrict__ wlog,
+                                     unsigned batch_no, int s_from, int rank0, bool late, int tid, int lane, int wave) {
+    const int min_lanes = late ? 64 : MRZ_BULK_MIN;  // (the commit asks when a whole window of 64 is clean)
+    mrz_slot *tab = C.tab;
+    const int smask = (int)C.slot_mask;
+    const int max_chain = (int)C.max_chain;
+    const int64_t better = (L.min_mask << 1) | 1;
+    const bool loose = L.tag_mask != better;
+    const int nb = S->nb;
+    const int64_t cw_base = S->cw_base;
+    const bool have = tid < nb && tid >= s_from;
+    const int f = have ? S->lf[tid] : 0;
+    const bool act = (f & MRZ_LF_ACT) != 0, ins = act && (f & MRZ_LF_INS);
+    const bool cplx = (f & MRZ_LF_CPLX) != 0, lng = (f & MRZ_LF_LONG) != 0;
+    bool conf = (f & MRZ_LF_CONF) != 0;
+    const int64_t q = S->q[tid];
+    const int kind = S->kind[tid], kind2 = S->kind2[tid];
+    const int wslot0 = S->wslot[tid], w2 = S->w2[tid];
+    if (late && act && !cplx && !conf) {
+        const int d0 = S->dep0[tid], d1 = S->dep1[tid], d2 = S->dep2[tid];
+        if ((d0 < s_from && S->exec[d0] != 1) || (d1 < s_from && S->exec[d1] != 1) || (d2 < s_from && S->exec[d2] != 1))
+            conf = true;
+        const int nx = S->xw_n;
+        const int h = S->h[tid], len1 = S->len1[tid], h2 = S->h2[tid], len2 = S->len2[tid];
+        for (int k = 0; k < nx && !conf; k++) {
+            const int sl = S->xw_slot[k];
+            if ((len1 > 0 && mrz_in_range(sl, h, len1, smask)) || (len2 > 0 && mrz_in_range(sl, h2, len2, smask))) conf = true;
+        }
+    }
+    const int bm = act ? (S->bhm[tid] & 255) : 0;
+    const bool stopish = have && act && (cplx || conf || lng || S->blen[tid] > 0);
+    {
+        const int fs = mrz_wave_first(stopish, wave, nb);
+        if (lane == 0) S->wmin[0][wave] = fs;
+    }
+    mrz_prep_sync<NW>();
+    int x0 = S->wmin[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) x0 = S->wmin[0][w] < x0 ? S->wmin[0][w] : x0;
+    if (L.cur_len >= MRZ_MIN_MATCH) x0 = 0;  // a pending match may be emitted at any lane
+    const int s0 = s_from;
+    if (x0 - s0 >= min_lanes) {
+        const bool inb = tid >= s0 && tid < x0;
+        const bool a_ins = inb && ins;
+        const bool a_ev = a_ins && kind == 3;
+        const int d = a_ins ? (kind == 0 ? 1 : (kind == 2 ? (kind2 == 0 ? 1 : 0) : 0)) : 0;
+        int dummy;
+        const int i1 = mrz_wide_incl<NW>(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wt1, lane, wave, &dummy);
+        int wslot = wslot0;
+        if (a_ev) {
+            const int er = ((i1 >> 10) & 1023) - 1;
+            const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
+            wslot = (int)(mrz_pool_get(S, tid, vr) >> MRZ_OFF_BITS);
+        }
+        int64_t c_before = L.count + ((i1 & 1023) - d);
+        if (c_before > C.limit) c_before = C.limit;
+        const bool cull = a_ins && (c_before + d > C.limit);
+        const int i2 = mrz_wide_incl<NW>((cull ? 1 : 0) | ((inb && act ? bm : 0) << 10), S->wt3, lane, wave, &dummy);
+        int cslot = -1;
+        bool overflow = false;
+        if (cull) {
+            const int cr = rank0 + (i2 & 1023) - 1;
+            if (cr >= S->cwcum[MRZ_CW_WORDS])
+                overflow = true;
+            else
+                cslot = mrz_cw_slot(S, cw_base, cr);
+        }
+        {
+            const int fo_ = mrz_wave_first(overflow, wave, MRZ_W);
+            const int fc_ = mrz_wave_first(cull, wave, MRZ_W);
+            if (lane == 0) {
+                S->wmin[1][wave] = fo_;
+                S->wmin[2][wave] = fc_;
+            }
+        }
+        mrz_prep_sync<NW>();
+        int o_lane = S->wmin[1][0], c_lane = S->wmin[2][0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            o_lane = S->wmin[1][w] < o_lane ? S->wmin[1][w] : o_lane;
+            c_lane = S->wmin[2][w] < c_lane ? S->wmin[2][w] : c_lane;
+        }
+        int y = x0;
+        bool endb = false;
+        if (o_lane < y) {
+            y = o_lane;
+            endb = true;
+        }
+        if (loose && c_lane + 1 <= y) {  // the first cull ever switches the insert mask (:583)
+            y = c_lane + 1;
+            endb = true;
+        }
+        if (tid >= s0 && tid < y) {
+            if (a_ins) {
+                const unsigned stamp = batch_no + 1u;
+                if (kind == 2 && S->supp_w2[tid] >= y) {
+                    mrz_slot oc;
+                    oc.off = S->occ_off[tid];
+                    oc.t = S->occ_t[tid];
+                    tab[w2] = oc;
+                    wlog[w2 >> MRZ_WLOG_SHIFT] = stamp;
+                }
+                if (S->supp_w[tid] >= y) {
+                    mrz_slot nw;
+                    nw.off = q;
+                    nw.t = S->t[tid];
+                    tab[wslot] = nw;
+                    wlog[wslot >> MRZ_WLOG_SHIFT] = stamp;
+                }
+                if (cslot >= 0) {
+                    mrz_slot z;
+                    z.off = 0;
+                    z.t = 0;
+                    tab[cslot] = z;
+                    wlog[cslot >> MRZ_WLOG_SHIFT] = stamp;
+                }
+            }
+            S->exec[tid] = 1;
+        }
+        if (y > s0 && tid == y - 1) {
+            S->bulk_a1 = i1;
+            S->bulk_a2 = i2;
+        }
+        if (tid == 0) {
+            S->bulk_y = y > s0 ? y : 0;
+            S->bulk_end = endb ? 1 : 0;
+        }
+    } else if (tid == 0)
+        S->bulk_y = 0;
+    mrz_prep_sync<NW>();
+}
+
 // PRE-COMMIT of a prepared batch: all threads of the workgroup, once the matcher's state L is this workgroup's to move
 // (its turn has come).  Brings the prepared lanes up to date with what has happened since they were prepared:
 //   * lanes at or before L.p are dropped (an emitted match covers them);
@@ -1231,11 +1373,10 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
 // them at once -- scans for victim_round, hash_count and the cull ranks as in the commit proper -- and hand wave 0 the
 // totals.  Match-free stretches (noise) are committed entirely here.
 template <int NW>
-__device__ static void mrz_wide_precommit(const mrz_cfg &C, const mrz_lead &L, mrz_wide_lds *S, unsigned *__restrict__ wlog,
+__device__ static __attribute__((noinline)) void mrz_wide_precommit(const mrz_cfg &C, const mrz_lead &L, mrz_wide_lds *S, unsigned *__restrict__ wlog,
                                           unsigned snap, unsigned batch_no, int tid, int lane, int wave, int64_t *stat) {
     mrz_slot *tab = C.tab;
     const int smask = (int)C.slot_mask;
-    const int max_chain = (int)C.max_chain;
     const int64_t better = (L.min_mask << 1) | 1;
     const bool loose = L.tag_mask != better;
     const int nb = S->nb;
@@ -1260,6 +1401,11 @@ __device__ static void mrz_wide_precommit(const mrz_cfg &C, const mrz_lead &L, m
         // an overlay walk that has assumed the writes of a lane that is not going to run (the matcher is past it)
         const int d0 = S->dep0[tid], d1 = S->dep1[tid], d2 = S->dep2[tid];
         if ((d0 < MRZ_W && S->q[d0] <= L.p) || (d1 < MRZ_W && S->q[d1] <= L.p) || (d2 < MRZ_W && S->q[d2] <= L.p)) conf = true;
+    }
+    {
+        // first lane behind the matcher's position (the lanes are in position order); read after the barriers below
+        const int fl = mrz_wave_first(live, wave, nb);
+        if (lane == 0) S->wmin[3][wave] = fl;
     }
     ST_COUNT(MRZ_ST_W_DROP, have && !live);
     const bool conf_before = conf;
@@ -1355,115 +1501,15 @@ __device__ static void mrz_wide_precommit(const mrz_cfg &C, const mrz_lead &L, m
         }
 
         PROF_ADD(MRZ_ST_T_PC_BEST);
-        // ---- E0: bulk commit
-        const bool stopish = have && act && (cplx || conf || lng || bl > 0);
-        {
-            const int fs = mrz_wave_first(stopish, wave, nb);
-            const int fl = mrz_wave_first(live, wave, nb);
-            if (lane == 0) {
-                S->wmin[0][wave] = fs;
-                S->wmin[3][wave] = fl;
-            }
-        }
-        mrz_prep_sync<NW>();
-        int x0 = S->wmin[0][0], s0 = S->wmin[3][0];
-#pragma unroll
-        for (int w = 1; w < NW; w++) {
-            x0 = S->wmin[0][w] < x0 ? S->wmin[0][w] : x0;
-            s0 = S->wmin[3][w] < s0 ? S->wmin[3][w] : s0;
-        }
-        if (L.cur_len >= MRZ_MIN_MATCH) x0 = 0;  // a pending match may be emitted at any lane
-        if (tid == 0) S->first_live = s0;
-        if (x0 - s0 >= MRZ_BULK_MIN) {
-            const bool inb = tid >= s0 && tid < x0;
-            const bool a_ins = inb && ins;
-            const bool a_ev = a_ins && kind == 3;
-            const int d = a_ins ? (kind == 0 ? 1 : (kind == 2 ? (kind2 == 0 ? 1 : 0) : 0)) : 0;
-            int dummy;
-            const int i1 = mrz_wide_incl<NW>(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wt1, lane, wave, &dummy);
-            int wslot = wslot0;
-            if (a_ev) {
-                const int er = ((i1 >> 10) & 1023) - 1;
-                const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
-                wslot = (int)(mrz_pool_get(S, tid, vr) >> MRZ_OFF_BITS);
-            }
-            int64_t c_before = L.count + ((i1 & 1023) - d);
-            if (c_before > C.limit) c_before = C.limit;
-            const bool cull = a_ins && (c_before + d > C.limit);
-            const int i2 = mrz_wide_incl<NW>((cull ? 1 : 0) | ((inb && act ? bm : 0) << 10), S->wt3, lane, wave, &dummy);
-            int cslot = -1;
-            bool overflow = false;
-            if (cull) {
-                const int cr = (i2 & 1023) - 1;
-                if (cr >= S->cwcum[MRZ_CW_WORDS])
-                    overflow = true;
-                else
-                    cslot = mrz_cw_slot(S, cw_base, cr);
-            }
-            {
-                const int fo_ = mrz_wave_first(overflow, wave, MRZ_W);
-                const int fc_ = mrz_wave_first(cull, wave, MRZ_W);
-                if (lane == 0) {
-                    S->wmin[1][wave] = fo_;
-                    S->wmin[2][wave] = fc_;
-                }
-            }
-            mrz_prep_sync<NW>();
-            int o_lane = S->wmin[1][0], c_lane = S->wmin[2][0];
-#pragma unroll
-            for (int w = 1; w < NW; w++) {
-                o_lane = S->wmin[1][w] < o_lane ? S->wmin[1][w] : o_lane;
-                c_lane = S->wmin[2][w] < c_lane ? S->wmin[2][w] : c_lane;
-            }
-            int y = x0;
-            bool endb = false;
-            if (o_lane < y) {
-                y = o_lane;
-                endb = true;
-            }
-            if (loose && c_lane + 1 <= y) {  // the first cull ever switches the insert mask (:583)
-                y = c_lane + 1;
-                endb = true;
-            }
-            if (tid >= s0 && tid < y) {
-                if (a_ins) {
-                    const unsigned stamp = batch_no + 1u;
-                    if (kind == 2 && S->supp_w2[tid] >= y) {
-                        mrz_slot oc;
-                        oc.off = S->occ_off[tid];
-                        oc.t = S->occ_t[tid];
-                        tab[w2] = oc;
-                        wlog[w2 >> MRZ_WLOG_SHIFT] = stamp;
-                    }
-                    if (S->supp_w[tid] >= y) {
-                        mrz_slot nw;
-                        nw.off = q;
-                        nw.t = S->t[tid];
-                        tab[wslot] = nw;
-                        wlog[wslot >> MRZ_WLOG_SHIFT] = stamp;
-                    }
-                    if (cslot >= 0) {
-                        mrz_slot z;
-                        z.off = 0;
-                        z.t = 0;
-                        tab[cslot] = z;
-                        wlog[cslot >> MRZ_WLOG_SHIFT] = stamp;
-                    }
-                }
-                S->exec[tid] = 1;
-            }
-            if (y > s0 && tid == y - 1) {
-                S->bulk_a1 = i1;
-                S->bulk_a2 = i2;
-            }
-            if (tid == 0) {
-                S->bulk_y = y > s0 ? y : 0;
-                S->bulk_end = endb ? 1 : 0;
-            }
-        } else if (tid == 0)
-            S->bulk_y = 0;
     }
-    mrz_prep_sync<NW>();
+    int s0 = S->wmin[3][0];  // (written before the cull window's barriers)
+#pragma unroll
+    for (int w = 1; w < NW; w++) s0 = S->wmin[3][w] < s0 ? S->wmin[3][w] : s0;
+    if (tid == 0) {
+        S->first_live = s0;
+        S->rank0 = 0;
+    }
+    mrz_wide_bulk<NW>(C, L, S, wlog, batch_no, s0, 0, false, tid, lane, wave);
     PROF_ADD(MRZ_ST_T_PC_BULK);
 }
 
@@ -1488,8 +1534,11 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
     (void)total;
     PROF_T0();
     if (nb == 0) return;
-    int s = mrz_uni(S->first_live), cw_used = 0, committed = 0, iters = 0;
+    const int rank0 = mrz_uni(S->rank0);
+    int s = mrz_uni(S->first_live), cw_used = rank0, committed = 0, iters = 0;
     bool bulk_end = false;
+    bool moved = false;  // something has been committed or handed over since the last bulk step
+    ret->rebulk = false;
     {
         // what the pre-commit step has committed in bulk already: lanes [first_live, y)
         const int y = mrz_uni(S->bulk_y);
@@ -1502,9 +1551,9 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             if (cnew > C.limit) cnew = C.limit;
             L.count = cnew;
             if (csum) {
-                L.clean_ptr = mrz_cw_slot(S, cw_base, csum - 1);
+                L.clean_ptr = mrz_cw_slot(S, cw_base, rank0 + csum - 1);
                 L.tag_mask = better;
-                cw_used = csum;
+                cw_used = rank0 + csum;
             }
             if (esum) L.victim_round = (int64_t)(((unsigned)L.victim_round + (unsigned)esum) % (unsigned)max_chain);
             L.tag_misses += msum;
@@ -1595,6 +1644,7 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                 const bool okc = mrz_seq_candidate(C, L, &S->coop, mrz_uni64(S->t[s]), lane, stat);
                 PROF_ADD(MRZ_ST_H_CAND);
                 committed += 1;
+                moved = true;
                 if (!okc) {
                     ret->ok = false;
                     break;
@@ -1700,6 +1750,27 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             continue;
         }
 
+        // a whole window of clean lanes without a match, and more behind it: all waves commit such a stretch faster
+        bool ask_bulk = moved && nseg == 64 && nb - s >= 64 + MRZ_W / 8 && L.cur_len < MRZ_MIN_MATCH &&
+                        !__ballot(have && act && blen > 0);
+        if (ask_bulk) {
+            // ... and the lanes of the window behind this one look clean as well (as prepared: a peek, not the rules)
+            const int i2 = s + 64 + lane;
+            const bool in2 = i2 < nb && lane < MRZ_W / 8;
+            const int f2 = in2 ? S->lf[i2] : 0;
+            const bool dirty2 = in2 && (f2 & MRZ_LF_ACT) && ((f2 & (MRZ_LF_CONF | MRZ_LF_CPLX | MRZ_LF_LONG)) || S->blen[i2] > 0);
+            if (__ballot(dirty2)) ask_bulk = false;
+        }
+        if (ask_bulk) {
+            ret->rebulk = true;
+            ST_ADD(MRZ_ST_REBULK, 1);
+            if (lane == 0) {
+                S->first_live = s;
+                S->rank0 = cw_used;
+            }
+            break;
+        }
+        moved = true;
         // ---- the segment [s, s + nseg): sequential quantities by wave scans ----------------------------------------
         ST_ADD(MRZ_ST_SEGMENTS, 1);
         const bool inseg = lane < nseg;

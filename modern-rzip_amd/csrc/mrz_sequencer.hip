@@ -306,6 +306,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             break;
         }
         // ---- this workgroup's turn: the matcher state is ours ----------------------------------------------------
+#ifdef MRZ_SEQ_PROFILE
+        const int64_t turn_t0 = (int64_t)__builtin_amdgcn_s_memtime();
+#endif
         L = G->L;
         gseq = G->gseq;
         gnw = G->gnw;
@@ -339,13 +342,28 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 PROF_T0R();
                 mrz_wide_precommit<MRZ_SEQ_WAVES>(C, L, S, wlog, snap, (unsigned)b, tid, lane, wave, stat);
                 PROF_ADD(MRZ_ST_T_PRECOMMIT);
+                mrz_wide_ret r;
+                r.used = 0;
+                r.ok = true;
+                r.whole = true;
+                r.stop_batch = false;
+                r.rebulk = false;
+                for (;;) {
+                    // wave 0 commits; when it finds a long clean stretch behind a hand-over it has all waves commit that
+                    if (wave == 0) {
+                        mrz_wide_commit(C, L, S, wlog, (unsigned)b, lane, stat, &r);
+                        if (lane == 0) {
+                            S->ctl[4] = r.rebulk ? 1 : 0;
+                            if (r.rebulk) S->lead = L;
+                        }
+                    }
+                    __syncthreads();
+                    if (!mrz_uni(S->ctl[4])) break;
+                    if (wave != 0) L = S->lead;
+                    mrz_wide_bulk<MRZ_SEQ_WAVES>(C, L, S, wlog, (unsigned)b, mrz_uni(S->first_live), mrz_uni(S->rank0), true, tid,
+                                                 lane, wave);
+                }
                 if (wave == 0) {
-                    mrz_wide_ret r;
-                    r.used = 0;
-                    r.ok = true;
-                    r.whole = true;
-                    r.stop_batch = false;
-                    mrz_wide_commit(C, L, S, wlog, (unsigned)b, lane, stat, &r);
                     const int64_t w_end = mrz_uni64(S->w_end), adv_to = mrz_uni64(S->adv_to);
                     const int total = mrz_uni(S->total);
                     const bool masks_moved = L.min_mask != mrz_uni64(S->prep_min_mask) || L.tag_mask != mrz_uni64(S->prep_tag_mask);
@@ -454,6 +472,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             MRZ_WAIT_STORES();
             __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef MRZ_SEQ_PROFILE
+        stat[MRZ_ST_T_TURNWORK] += (int64_t)__builtin_amdgcn_s_memtime() - turn_t0;
+#endif
         b += (unsigned long long)n_act;
         __syncthreads();
     }
