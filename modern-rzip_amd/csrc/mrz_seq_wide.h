@@ -39,15 +39,20 @@
 #define MRZ_PAIR_MAX (MRZ_POOL * 4)
 #define MRZ_BH_SIZE 2048              // block-hash entries (64-slot blocks written by this batch)
 #define MRZ_BH_WRITERS 5
-#define MRZ_OV_ROUNDS 3               // overlay rounds of a preparation (a repaired writer makes its readers repairable)
+#define MRZ_BHO_MAX 192
+#ifndef MRZ_OV_ROUNDS
+#define MRZ_OV_ROUNDS 3  // overlay rounds of a preparation (a repaired writer makes its readers repairable)
+#endif
 #define MRZ_CW_WORDS 32               // cull window: 32 x 64 slots ahead of tag_clean_ptr
 #define MRZ_NW_MAX 192
 #define MRZ_XW_MAX 48
 #ifndef MRZ_BULK_MIN
 #define MRZ_BULK_MIN 96              // leading lanes worth a workgroup-wide bulk commit
 #endif
-#define MRZ_OV_MAX 6   // overlay entries of one lane: up to 3 earlier writers, insert + occupant slot each
-#define MRZ_WR_MAX 3
+#ifndef MRZ_WR_MAX
+#define MRZ_WR_MAX 3   // earlier writers of this batch an overlay walk can take into account
+#endif
+#define MRZ_OV_MAX (2 * MRZ_WR_MAX)  // overlay entries of one lane: insert + occupant slot of each writer
 #define MRZ_OFF_BITS 40
 #define MRZ_OFF_MASK ((1ull << MRZ_OFF_BITS) - 1)
 
@@ -86,7 +91,7 @@ struct mrz_wide_lds {
     int64_t blen[MRZ_W], boff[MRZ_W];  // best match of the lane's entries under the last_match of the preparation
     int brev[MRZ_W];
     unsigned short bhm[MRZ_W];         // tag_hits << 8 | tag_misses of that look-up
-    unsigned short dep0[MRZ_W], dep1[MRZ_W], dep2[MRZ_W];  // lanes whose speculated writes an overlay walk has assumed
+    unsigned short dep[MRZ_WR_MAX][MRZ_W];  // lanes whose speculated writes an overlay walk has assumed (MRZ_W: none)
     unsigned char exec[MRZ_W];         // 0 not yet, 1 committed as prepared, 2 dropped / went through the cooperative path
     int xw_n;                          // slots written by cooperative hand-overs inside this batch
     int xw_slot[MRZ_XW_MAX];
@@ -97,6 +102,9 @@ struct mrz_wide_lds {
     unsigned bh_key[MRZ_BH_SIZE];
     unsigned bh_cnt[MRZ_BH_SIZE];
     unsigned short bh_lane[MRZ_BH_SIZE][MRZ_BH_WRITERS];
+    int bho_n;  // writers beyond MRZ_BH_WRITERS of a block: (block key, lane)
+    unsigned bho_key[MRZ_BHO_MAX];
+    unsigned short bho_lane[MRZ_BHO_MAX];
     mrz_u64 cw[MRZ_CW_WORDS];
     int cwcum[MRZ_CW_WORDS + 1];
     int cw_list[MRZ_W];   // slot of the r-th failing entry of the window, r < min(cwcum[last], MRZ_W)
@@ -630,7 +638,16 @@ __device__ static void mrz_bh_add(mrz_wide_lds *S, int slot, int gl) {
         const unsigned k = atomicCAS(&S->bh_key[i], 0u, key);
         if (k == 0u || k == key) {
             const unsigned c = atomicAdd(&S->bh_cnt[i], 1u);
-            if (c < MRZ_BH_WRITERS) S->bh_lane[i][c] = (unsigned short)gl;
+            if (c < MRZ_BH_WRITERS)
+                S->bh_lane[i][c] = (unsigned short)gl;
+            else {
+                // (many lanes of one tag appending to one chain) the rest of a crowded block's writers: one list
+                const int at = atomicAdd(&S->bho_n, 1);
+                if (at < MRZ_BHO_MAX) {
+                    S->bho_key[at] = key;
+                    S->bho_lane[at] = (unsigned short)gl;
+                }
+            }
             return;
         }
         i = (i + 1) & (MRZ_BH_SIZE - 1);
@@ -671,10 +688,23 @@ __device__ static int mrz_bh_readers(const mrz_wide_lds *S, int gl, int a, int l
                 const unsigned k = S->bh_key[i];
                 if (k == 0u) break;
                 if (k == key) {
-                    const unsigned c = S->bh_cnt[i];
+                    unsigned c = S->bh_cnt[i];
                     if (c > MRZ_BH_WRITERS) {
-                        // more writers than recorded: an earlier one may be among them
-                        return -1;
+                        // more writers than the entry records: the rest are in the overflow list
+                        const int no = S->bho_n;
+                        if (no > MRZ_BHO_MAX) return -1;
+                        for (int z = 0; z < no; z++) {
+                            if (S->bho_key[z] != key) continue;
+                            const int wl = S->bho_lane[z];
+                            if (wl >= gl || !mrz_writes_hit(S, wl, a, la, b, lb, smask)) continue;
+                            bool dup = false;
+                            for (int y = 0; y < found && y < MRZ_WR_MAX; y++) dup = dup || wr[y] == wl;
+                            if (!dup) {
+                                if (found < MRZ_WR_MAX) wr[found] = wl;
+                                found++;
+                            }
+                        }
+                        c = MRZ_BH_WRITERS;
                     }
                     for (unsigned j = 0; j < c; j++) {
                         const int wl = S->bh_lane[i][j];
@@ -806,6 +836,7 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     }
     if (tid == 0) {
         S->pool_top = 0;
+        S->bho_n = 0;
         S->nw_cnt = 0;
         S->xw_n = 0;
     }
@@ -898,7 +929,9 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     ST_COUNT(MRZ_ST_X_SAME, cplx && wl.why == 4);
     int h = (int)(t & C.slot_mask);
     int len1 = (act && !cplx) ? ((wl.fe - h) & smask) + 1 : 0;
-    int dep0 = -1, dep1 = -1, dep2 = -1;  // lanes whose writes this lane's (overlay) walk has assumed
+    int dep[MRZ_WR_MAX];  // lanes whose writes this lane's (overlay) walk has assumed
+#pragma unroll
+    for (int k = 0; k < MRZ_WR_MAX; k++) dep[k] = -1;
 
     // post-walk rules that involve the cull window; publishes the lane's facts
     auto post_walk = [&]() {
@@ -947,7 +980,9 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     }
     PROF_ADD(MRZ_ST_T_WALK);
     mrz_prep_sync<NW>();
-    int wr[MRZ_WR_MAX] = { -1, -1, -1 };
+    int wr[MRZ_WR_MAX];
+#pragma unroll
+    for (int k = 0; k < MRZ_WR_MAX; k++) wr[k] = -1;
     int nwr = 0;
     if (act && !cplx) {
         nwr = mrz_bh_readers(S, tid, h, len1, wl.h2, wl.len2, smask, wr);
@@ -1001,18 +1036,15 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
         }
         if (elig) {
             // in lane order: a later writer's store is the one that stays
-#define MRZ_CSWAP(a, b)            \
-    if (wr[a] > wr[b]) {           \
-        const int z__ = wr[a];     \
-        wr[a] = wr[b];             \
-        wr[b] = z__;               \
-    }
-            if (nwr >= 2) MRZ_CSWAP(0, 1)
-            if (nwr >= 3) {
-                MRZ_CSWAP(1, 2)
-                MRZ_CSWAP(0, 1)
-            }
-#undef MRZ_CSWAP
+#pragma unroll
+            for (int x = 1; x < MRZ_WR_MAX; x++)
+#pragma unroll
+                for (int y2 = MRZ_WR_MAX - 1; y2 >= 1; y2--)
+                    if (y2 < nwr && wr[y2 - 1] > wr[y2]) {
+                        const int z__ = wr[y2 - 1];
+                        wr[y2 - 1] = wr[y2];
+                        wr[y2] = z__;
+                    }
 #pragma unroll
             for (int k = 0; k < MRZ_WR_MAX; k++) {
                 if (k >= nwr) continue;
@@ -1076,7 +1108,8 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
                 const int nlen1 = good ? ((wn.fe - h) & smask) + 1 : 0;
                 if (good) {
                     // no other earlier writer may reach into what it has read now
-                    int wr2[MRZ_WR_MAX] = { -1, -1, -1 };
+                    int wr2[MRZ_WR_MAX];
+                    for (int k = 0; k < MRZ_WR_MAX; k++) wr2[k] = -1;
                     const int n2 = mrz_bh_readers(S, tid, h, nlen1, wn.h2, wn.len2, smask, wr2);
                     if (n2 < 0 || n2 > nwr) good = false;
                     for (int k = 0; k < n2 && k < MRZ_WR_MAX && good; k++) {
@@ -1118,9 +1151,8 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
                     wl = wn;
                     len1 = nlen1;
                     conf = false;
-                    dep0 = wr[0];
-                    dep1 = nwr >= 2 ? wr[1] : -1;
-                    dep2 = nwr >= 3 ? wr[2] : -1;
+#pragma unroll
+                    for (int k = 0; k < MRZ_WR_MAX; k++) dep[k] = k < nwr ? wr[k] : -1;
                     S->len1[tid] = len1;
                     S->h2[tid] = wl.h2;
                     S->len2[tid] = wl.len2;
@@ -1143,7 +1175,10 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
             if (act && !cplx && !conf) {
                 for (int k = 0; k < nw; k++) {
                     const int wlane = S->nw_lane[k];
-                    if (wlane >= tid || wlane == dep0 || wlane == dep1 || wlane == dep2) continue;
+                    bool mine = false;
+#pragma unroll
+                    for (int z = 0; z < MRZ_WR_MAX; z++) mine = mine || wlane == dep[z];
+                    if (wlane >= tid || mine) continue;
                     const int sl = S->nw_slot[k];
                     if ((len1 > 0 && mrz_in_range(sl, h, len1, smask)) || (wl.len2 > 0 && mrz_in_range(sl, wl.h2, wl.len2, smask))) {
                         conf = true;
@@ -1209,9 +1244,8 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
             const int nsx = wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX;
             for (int k = 0; k < nsx; k++) revs = revs || ((S->pool[S->chunk_id[tid][k >> 2]].raw[k & 3] >> 8) & 127) != 0;
         }
-        S->dep0[tid] = (unsigned short)(dep0 >= 0 ? dep0 : MRZ_W);
-        S->dep1[tid] = (unsigned short)(dep1 >= 0 ? dep1 : MRZ_W);
-        S->dep2[tid] = (unsigned short)(dep2 >= 0 ? dep2 : MRZ_W);
+#pragma unroll
+        for (int k = 0; k < MRZ_WR_MAX; k++) S->dep[k][tid] = (unsigned short)(dep[k] >= 0 ? dep[k] : MRZ_W);
         S->len1[tid] = (act && !cplx) ? len1 : 0;
         S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
         S->lf[tid] = (unsigned char)((conf ? MRZ_LF_CONF : 0) | (cplx ? MRZ_LF_CPLX : 0) | (act ? MRZ_LF_ACT : 0) |
@@ -1247,9 +1281,11 @@ __device__ static __attribute__((noinline)) void mrz_wide_bulk(const mrz_cfg &C,
     const int kind = S->kind[tid], kind2 = S->kind2[tid];
     const int wslot0 = S->wslot[tid], w2 = S->w2[tid];
     if (late && act && !cplx && !conf) {
-        const int d0 = S->dep0[tid], d1 = S->dep1[tid], d2 = S->dep2[tid];
-        if ((d0 < s_from && S->exec[d0] != 1) || (d1 < s_from && S->exec[d1] != 1) || (d2 < s_from && S->exec[d2] != 1))
-            conf = true;
+#pragma unroll
+        for (int k = 0; k < MRZ_WR_MAX; k++) {
+            const int dk = S->dep[k][tid];
+            if (dk < s_from && S->exec[dk] != 1) conf = true;
+        }
         const int nx = S->xw_n;
         const int h = S->h[tid], len1 = S->len1[tid], h2 = S->h2[tid], len2 = S->len2[tid];
         for (int k = 0; k < nx && !conf; k++) {
@@ -1399,8 +1435,11 @@ __device__ static __attribute__((noinline)) void mrz_wide_precommit(const mrz_cf
     const int wslot0 = S->wslot[tid], w2 = S->w2[tid];
     if (act && !cplx && !conf) {
         // an overlay walk that has assumed the writes of a lane that is not going to run (the matcher is past it)
-        const int d0 = S->dep0[tid], d1 = S->dep1[tid], d2 = S->dep2[tid];
-        if ((d0 < MRZ_W && S->q[d0] <= L.p) || (d1 < MRZ_W && S->q[d1] <= L.p) || (d2 < MRZ_W && S->q[d2] <= L.p)) conf = true;
+#pragma unroll
+        for (int k = 0; k < MRZ_WR_MAX; k++) {
+            const int dk = S->dep[k][tid];
+            if (dk < MRZ_W && S->q[dk] <= L.p) conf = true;
+        }
     }
     {
         // first lane behind the matcher's position (the lanes are in position order); read after the barriers below
@@ -1588,8 +1627,11 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
         // cooperative hand-over inside this batch wrote into what it has read
         if (have && act && !cplx && !conf) {
             // (a lane of this very window either commits together with this one or cuts the segment before it)
-            const int d0 = S->dep0[ii], d1 = S->dep1[ii], d2 = S->dep2[ii];
-            if ((d0 < s && S->exec[d0] != 1) || (d1 < s && S->exec[d1] != 1) || (d2 < s && S->exec[d2] != 1)) conf = true;
+#pragma unroll
+            for (int k = 0; k < MRZ_WR_MAX; k++) {
+                const int dk = S->dep[k][ii];
+                if (dk < s && S->exec[dk] != 1) conf = true;
+            }
             const int nx = S->xw_n;
             if (nx > 0) {
                 const int h = S->h[ii], len1 = S->len1[ii], h2 = S->h2[ii], len2 = S->len2[ii];
