@@ -622,7 +622,19 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                          "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit", "reprep", "w_stale", "w_drop", "reset",
                                          "t_turn", "t_prep", "t_precommit", "e_mask", "e_cull", "e_xw", "e_inwin", "e_window", "e_bulk",
                                          "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk", "t_turnwork", "t_snap", "rebulk" };
-        for (int k = 0; k < 96; k++) if (names[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
+        // (the narrow engine keeps its own list: MRZ_PRINT_PROF=narrow prints with its names; meaningful when
+        // MRZ_SEQ_ENGINE=narrow pinned the engine)
+        static const char *narrow_names[96] = { "batches", "batch_lanes", "seq", "cut_long", "cut_walk", "cut_conflict", "cut_cull",
+                                                "batch_emits", "cut_cascade", "pairs", "batch_formed", "t_form", "t_walk", "t_walk2",
+                                                "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window", "t_long", "t_fold",
+                                                "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
+                                                "f_fold", "f_helper", "h_fields", "h_fwd", "h_bwd", "h_drain", "h_rounds", "s_tab",
+                                                "s_pair", "s_ins" };
+        const bool nn = !strcmp(getenv("MRZ_PRINT_PROF"), "narrow");
+        for (int k = 0; k < 96; k++) {
+            const char *nm = nn ? narrow_names[k] : names[k];
+            if (nm) fprintf(stderr, "seqstat %-12s %lld\n", nm, (long long)hs.prof[k]);
+        }
     }
     return MRZ_OK;
 }

@@ -8,7 +8,7 @@ from modern_rzip_amd import workloads as w
 PROF = "--prof" in sys.argv
 if PROF:
     sys.argv.remove("--prof")
-    os.environ["MRZ_PRINT_PROF"] = "1"
+    os.environ.setdefault("MRZ_PRINT_PROF", "1")
     LIB = m.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_prof", "libmrzgpu_prof.so"))
 else:
     LIB = m.load_library()
