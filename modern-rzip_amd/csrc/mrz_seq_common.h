@@ -939,6 +939,9 @@ __device__ static bool mrz_seq_candidate(const mrz_cfg &C, mrz_lead &L, mrz_coop
                     return false;
                 L.tag_hits += xh;
                 L.tag_misses += xm;
+#ifdef MRZ_DBG_HITS_COOP
+                if (lane == 0) MRZ_DBG_HITS_COOP(p, xh, xm);
+#endif
                 todo = rest;
                 PROF_T0R();
             }

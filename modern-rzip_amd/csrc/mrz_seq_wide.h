@@ -35,7 +35,7 @@
 #include "mrz_seq_common.h"
 
 #define MRZ_W MRZ_SEQ_THREADS
-#define MRZ_POOL 1024                 // chunks of 4 tag-equal entries
+#define MRZ_POOL (2 * MRZ_W)          // chunks of 4 tag-equal entries: 8 entries per lane on average (a lane holds up to 16)
 #define MRZ_PAIR_MAX (MRZ_POOL * 4)
 #define MRZ_BH_SIZE 2048              // block-hash entries (64-slot blocks written by this batch)
 #define MRZ_BH_WRITERS 5
@@ -70,7 +70,8 @@ struct mrz_wide_lds {
     int first_live;       // first lane behind L.p (where the commit starts or resumes)
     int rank0;            // culls of this batch's cull window used up before that lane
     long long snap64[10];
-    mrz_lead lead;        // the matcher's state after a commit, for the waves that did not run it  // the snapshot a preparation works from (token, epoch, window base, masks)
+    mrz_lead lead;        // the matcher's state after a commit, for the waves that did not run it
+    unsigned long long hand[32];  // the hand-over block of mrz_wide_shared: loaded at a turn, stored at its end  // the snapshot a preparation works from (token, epoch, window base, masks)
     int64_t prep_min_mask, prep_tag_mask;  // the masks the batch was prepared under
     int64_t cw_base, w_end, floor_prep;
     int64_t adv_to, scan_last;  // see mrz_wide_prep
@@ -204,7 +205,10 @@ __device__ __forceinline__ int mrz_wide_min_read(const int *wm) {
 
 // ---- tag-equal entries of a lane: chunks of 4 out of a pool in LDS ----
 __device__ __forceinline__ bool mrz_pool_put(mrz_wide_lds *S, int gl, int idx, int64_t off, int slot) {
-    if ((idx & 3) == 0 && (idx >> 2) >= S->nchunk[gl]) {  // a lane that walks again keeps its chunks
+    if ((idx >> 2) >= S->nchunk[gl]) {  // (a lane that walks again keeps its chunks)
+        // the chunk of this entry has not been handed out: now, if this is its first entry -- else the pool had run
+        // dry when it was asked for (the walk goes on counting, the lane is complex): nothing to store into
+        if ((idx & 3) != 0) return false;
         const int c = atomicAdd(&S->pool_top, 1);
         if (c >= MRZ_POOL) return false;
         S->chunk_id[gl][idx >> 2] = (unsigned short)c;
@@ -466,7 +470,7 @@ __device__ static void mrz_wide_walk(const mrz_cfg &C, mrz_wide_lds *S, bool go,
                         const int idx = nsame_o + __popcll(m_same & mrz_low_mask(lane));
                         if (idx < MRZ_SMAX) {
                             const int id = S->chunk_id[gl_o][idx >> 2];
-                            if (id == 0xffff)
+                            if (id == 0xffff || (idx >> 2) >= S->nchunk[gl_o])  // (never handed out: the pool had run dry)
                                 bad = true;
                             else
                                 S->pool[id].e[idx & 3] =
@@ -628,6 +632,24 @@ __device__ __forceinline__ bool mrz_ranges_meet(int a, int la, int b, int lb, in
     return la > 0 && lb > 0 && ((((b - a) & smask) < la) || (((a - b) & smask) < lb));
 }
 
+// -DMRZ_DBG_HITS (tools/dbg_runs.py): every counted look-up leaves its hits / misses, and every preparation and
+// pre-commit a signature of what it found, in a buffer indexed by position -- two runs that should be identical can
+// be compared position by position (this is how the dry-pool bug of mrz_pool_put was found)
+#ifdef MRZ_DBG_HITS
+__device__ unsigned *mrz_dbg_hits;  // per position: (hits << 16 | misses) added by whoever counts them, + 1<<31 per visit
+#define DBG_HITS(q, h, m) atomicAdd(&mrz_dbg_hits[(q)], ((unsigned)(h) << 16) | (unsigned)(m) | (1u << 28))
+__device__ long long mrz_dbg_n;  // positions: plane k of the buffer starts at k * mrz_dbg_n
+#define DBG_PLANE(k, q, v) atomicAdd(&mrz_dbg_hits[(long long)(k) * mrz_dbg_n + (q)], (unsigned)(v))
+#else
+#define DBG_HITS(q, h, m) ((void)0)
+#define DBG_PLANE(k, q, v) ((void)0)
+#endif
+// all of this wave's global stores have completed (acknowledged by the L2)
+#ifdef __HIP_DEVICE_COMPILE__
+#define MRZ_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define MRZ_STORES_DONE() ((void)0)
+#endif
 // ---- block hash of this batch's writes (phase B2) ----
 __device__ __forceinline__ unsigned mrz_bh_hash(unsigned block) { return (block * 2654435761u) >> (32 - 11); }
 
@@ -1250,6 +1272,21 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
         S->len2[tid] = (act && !cplx) ? wl.len2 : 0;
         S->lf[tid] = (unsigned char)((conf ? MRZ_LF_CONF : 0) | (cplx ? MRZ_LF_CPLX : 0) | (act ? MRZ_LF_ACT : 0) |
                                      (ins ? MRZ_LF_INS : 0) | (revs ? MRZ_LF_REVS : 0));
+#ifdef MRZ_DBG_HITS
+        if (have) {
+            unsigned hsh = (unsigned)(conf ? 1 : 0) | (cplx ? 2 : 0) | (ins ? 4 : 0) | (revs ? 8 : 0);
+            hsh = hsh * 31u + (unsigned)wl.nsame;
+            hsh = hsh * 31u + (unsigned)wl.wslot;
+            hsh = hsh * 31u + (unsigned)wl.kind;
+            hsh = hsh * 31u + (unsigned)len1;
+            if (act && !cplx && !conf)
+                for (int k = 0; k < (wl.nsame < MRZ_SMAX ? wl.nsame : MRZ_SMAX); k++) {
+                    const int c = S->chunk_id[tid][k >> 2];
+                    hsh = hsh * 31u + (unsigned)(S->pool[c].e[k & 3] & MRZ_OFF_MASK) * 7u + S->pool[c].raw[k & 3];
+                }
+            DBG_PLANE(1, q, hsh | 1u);
+        }
+#endif
     }
     mrz_prep_sync<NW>();
 }
@@ -1356,6 +1393,7 @@ __device__ static __attribute__((noinline)) void mrz_wide_bulk(const mrz_cfg &C,
             y = c_lane + 1;
             endb = true;
         }
+        if (tid >= s0 && tid < y && act) DBG_HITS(q, 0, bm);
         if (tid >= s0 && tid < y) {
             if (a_ins) {
                 const unsigned stamp = batch_no + 1u;
@@ -1393,6 +1431,9 @@ __device__ static __attribute__((noinline)) void mrz_wide_bulk(const mrz_cfg &C,
         }
     } else if (tid == 0)
         S->bulk_y = 0;
+    // the table stores above must have landed before anybody reads the table again (wave 0's hand-overs, the next
+    // preparation): a workgroup barrier alone does not wait for them
+    MRZ_STORES_DONE();
     mrz_prep_sync<NW>();
 }
 
@@ -1537,6 +1578,15 @@ __device__ static __attribute__((noinline)) void mrz_wide_precommit(const mrz_cf
             S->lf[tid] = (unsigned char)((conf ? MRZ_LF_CONF : 0) | (cplx ? MRZ_LF_CPLX : 0) | (act ? MRZ_LF_ACT : 0) |
                                          (ins ? MRZ_LF_INS : 0) | (lng ? MRZ_LF_LONG : 0) | (f0 & MRZ_LF_REVS));
             if (!live) S->exec[tid] = 2;
+#ifdef MRZ_DBG_HITS
+            if (live) {
+                unsigned hsh = (unsigned)(conf ? 1 : 0) | (cplx ? 2 : 0) | (lng ? 4 : 0);
+                hsh = hsh * 31u + (unsigned)bl;
+                hsh = hsh * 31u + (unsigned)bh * 17u + (unsigned)bm;
+                hsh = hsh * 31u + (unsigned)floor_p;
+                DBG_PLANE(2, q, hsh | 1u);
+            }
+#endif
         }
 
         PROF_ADD(MRZ_ST_T_PC_BEST);
@@ -1665,6 +1715,11 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                 lng = (f & MRZ_LF_LONG) != 0;
             }
         }
+#ifdef MRZ_DBG_HITS
+        int dbg_sub = 0;
+        if (have && act && !cplx && !conf)
+            dbg_sub = (i == res_lane && floor_p == res_floor) ? 3 : (((f & MRZ_LF_REVS) && (q - floor_p <= 64 || (floor_p != floor_prep && q - floor_prep <= 64))) ? 2 : 1);
+#endif
         const bool stop = have && act && (cplx || conf || lng);
         const mrz_u64 m_stop = __ballot(stop);
         int nseg = nb - s < 64 ? nb - s : 64;
@@ -1918,6 +1973,10 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
             const int a1 = mrz_lane_read(i1, y - 1), a2 = mrz_lane_read(i2, y - 1);
             const int dsum = a1 & 255, esum = (a1 >> 8) & 255, isum = (a1 >> 16) & 255;
             const int csum = a2 & 255, hsum = (a2 >> 8) & 4095, msum = (a2 >> 20) & 4095;
+            if (inseg && lane < y && act) DBG_HITS(q, bh, bm);
+#ifdef MRZ_DBG_HITS
+            if (inseg && lane < y && act) DBG_PLANE(3, q, ((unsigned)dbg_sub << 28) | ((unsigned)floor_p & 0xfffffffu));
+#endif
             L.inserts += isum;
             int64_t cnew = L.count + dsum;
             if (cnew > C.limit) cnew = C.limit;
@@ -2007,4 +2066,5 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
     ret->whole = s >= nb && !ret->stop_batch;
     ST_ADD(MRZ_ST_COMMITTED, committed);
     ret->used = committed;
+    MRZ_STORES_DONE();  // (before the barrier behind which the other waves may prepare the rest of the window)
 }

@@ -23,6 +23,11 @@
 // separate parallel kernels.
 //
 // Bound: latency -- a chain of dependent table probes, data probes and cross-CU hand-offs; DESIGN.md 4.2.
+#include <cstddef>
+#ifdef MRZ_DBG_HITS
+#define MRZ_DBG_HITS_COOP(q, h, m) atomicAdd(&mrz_dbg_hits[(q)], ((unsigned)(h) << 16) | (unsigned)(m) | (1u << 24))
+extern __device__ unsigned *mrz_dbg_hits;
+#endif
 #include "mrz_seq_wide.h"
 
 // ---- several sequencer workgroups taking turns ---------------------------------------------------------------
@@ -42,22 +47,31 @@
 #endif
 #define MRZ_TURN_SPIN_LIMIT (1ll << 27)
 
+// words of mrz_wide_shared.hand: the matcher state (mrz_lead, 16 words) and what goes with it
+enum { MRZ_H_L = 0, MRZ_H_GSEQ = 16, MRZ_H_FARM, MRZ_H_GNW, MRZ_H_PW, MRZ_H_SMALL, MRZ_H_EPOCH, MRZ_H_BWORD, MRZ_H_BBATCH,
+       MRZ_H_BPOS, MRZ_H_N = 32 };
+static_assert(sizeof(mrz_lead) == 16 * 8, "mrz_lead is handed over as 16 words");
+
 struct mrz_wide_shared {          // device memory, zeroed by the host before every launch
+    // one 128-byte line of control words (polled with agent-scope loads)
     unsigned long long token;     // batches committed so far = the batch whose turn it is
     unsigned long long quit;      // the launch is over (segment end, error)
     unsigned long long census;    // sequencer workgroups that have reported their XCC id
     unsigned long long n_active;  // set by workgroup 0 once the state below is valid: workgroups taking part
     int xcc[8];
     int active[8];                // compact index of sequencer workgroup j, or -1
-    // handed from committer to committer (plain stores before the token is released)
-    mrz_lead L;
-    unsigned long long gseq;
-    long long farm_hint;
-    int gnw, pw;                  // pw: bitmap words per batch window
-    int small_run, pad_;          // batches in a row that came out less than half full
-    long long epoch, base_word, base_batch;  // batch b covers words [base_word + (b - base_batch) * pw, + pw)
-    long long base_pos;                      // ... and nothing before this position (where the epoch began)
+    unsigned long long pad_[4];
+    // two lines handed from committer to committer: written by ONE store instruction of the committing wave (a word
+    // per lane, agent scope) before it passes the token on, read by ONE agent-scope load instruction of the next
+    // committer after it has seen the token -- served by the L2, never by a line some earlier load left in an L1.
+    //   [0, 16)  mrz_lead    [16] farm round counter   [17] farm hint   [18] helpers seen   [19] pw: bitmap words per
+    //   batch window   [20] batches in a row that came out less than half full   [21] epoch   [22] base_word
+    //   [23] base_batch: batch b of the epoch covers words [base_word + (b - base_batch) * pw, + pw)   [24] base_pos:
+    //   ... and nothing before this position (where the epoch began)
+    unsigned long long hand[MRZ_H_N];
 };
+static_assert(offsetof(mrz_wide_shared, hand) == 128, "the hand-over block has its own cache lines");
+
 
 #ifdef __HIP_DEVICE_COMPILE__
 #define MRZ_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
@@ -94,6 +108,11 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     const int lane = tid & 63;
     const int wave = mrz_uni(tid >> 6);
     mrz_seq_state *st = a.st;
+#ifdef MRZ_EMU_POISON_LDS
+    // (test emulator: LDS is not zero when a workgroup starts on the GPU)
+    if (tid == 0) memset((void *)S, MRZ_EMU_POISON_LDS, sizeof(*S));
+    __syncthreads();
+#endif
 
     if (st->finished || st->error) return;
     // which role: blocks 0, 8, 16, ... are sequencer workgroups (one XCD), the others compare-farm helpers
@@ -186,17 +205,20 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             L.tag_misses = st->tag_misses;
             L.last_len = 0;
             L.mbytes = 0;
-            G->L = L;
-            G->gseq = 0;
-            G->gnw = 0;
-            G->farm_hint = 0;
+            *(mrz_lead *)&S->hand[MRZ_H_L] = L;
             int64_t pos = L.p + 1;
             if (pos < seg_start) pos = seg_start;
-            G->epoch = 1;
-            G->base_word = (pos - seg_start) >> 6;
-            G->base_pos = pos;
-            G->base_batch = 0;
-            G->pw = mrz_words_per_batch(L.min_mask);
+            S->hand[MRZ_H_GSEQ] = 0;
+            S->hand[MRZ_H_FARM] = 0;
+            S->hand[MRZ_H_GNW] = 0;
+            S->hand[MRZ_H_PW] = (unsigned long long)mrz_words_per_batch(L.min_mask);
+            S->hand[MRZ_H_SMALL] = 0;
+            S->hand[MRZ_H_EPOCH] = 1;
+            S->hand[MRZ_H_BWORD] = (unsigned long long)((pos - seg_start) >> 6);
+            S->hand[MRZ_H_BBATCH] = 0;
+            S->hand[MRZ_H_BPOS] = (unsigned long long)pos;
+            for (int k = 0; k <= MRZ_H_BPOS; k++)
+                __hip_atomic_store(&G->hand[k], S->hand[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             MRZ_RELEASE_AGENT();
             __hip_atomic_store(&G->n_active, (unsigned long long)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -214,9 +236,11 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     my = mrz_uni(S->ctl[1]);
     if (n_act <= 0 || my < 0) return;  // not taking part
     const bool multi = n_act > 1;
-    const int64_t hint_p0 = G->L.p, hint_ev0 = G->L.n_events;
+    const int64_t hint_p0 = (int64_t)__hip_atomic_load(&G->hand[MRZ_H_L + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t hint_ev0 = (int64_t)__hip_atomic_load(&G->hand[MRZ_H_L + 10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    mrz_lead L = G->L;  // (every wave keeps a copy; only the committing turn changes it)
+    mrz_lead L;  // (every wave keeps a copy, loaded at each turn; only the committing wave changes it)
+    memset(&L, 0, sizeof(L));
     unsigned long long b = (unsigned long long)my;
     bool ok = true;
     while (true) {
@@ -227,13 +251,13 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             unsigned long long t0 = 0;
             for (int tries = 0; tries < 64; tries++) {
                 t0 = __hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                e = __hip_atomic_load(&G->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bw = __hip_atomic_load(&G->base_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bb = __hip_atomic_load(&G->base_batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bp = __hip_atomic_load(&G->base_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pw = __hip_atomic_load(&G->pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mm = __hip_atomic_load(&G->L.min_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tm = __hip_atomic_load(&G->L.tag_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e = (long long)__hip_atomic_load(&G->hand[MRZ_H_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bw = (long long)__hip_atomic_load(&G->hand[MRZ_H_BWORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bb = (long long)__hip_atomic_load(&G->hand[MRZ_H_BBATCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bp = (long long)__hip_atomic_load(&G->hand[MRZ_H_BPOS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pw = (int)__hip_atomic_load(&G->hand[MRZ_H_PW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mm = (long long)__hip_atomic_load(&G->hand[MRZ_H_L + 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tm = (long long)__hip_atomic_load(&G->hand[MRZ_H_L + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long t1 = __hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (t1 == t0) break;
             }
@@ -274,25 +298,31 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         // side is that no line of this CU's L1 outlives the hand-over.  Nothing is loaded through the L1 between here and
         // the token (the poll is an agent-scope load, which bypasses it; the other waves sit at the barrier), so the
         // invalidate is issued now and completes while the token is awaited.
-        if (tid == 0) {
-            if (multi) MRZ_ACQUIRE_AGENT();
-            long long spins = 0;
-            int verdict = 1;
-            while (true) {
-                const unsigned long long tk = __hip_atomic_load(&G->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tk == b) break;
-                if (__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    verdict = 0;
-                    break;
+        if (wave == 0) {
+            if (lane == 0) {
+                if (multi) MRZ_ACQUIRE_AGENT();
+                long long spins = 0;
+                int verdict = 1;
+                while (true) {
+                    const unsigned long long tk = __hip_atomic_load(&G->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tk == b) break;
+                    if (__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        verdict = 0;
+                        break;
+                    }
+                    if (spins++ > MRZ_TURN_SPIN_LIMIT) {  // cannot happen: every turn ends in a token or in quit
+                        verdict = -1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
                 }
-                if (spins++ > MRZ_TURN_SPIN_LIMIT) {  // cannot happen: every turn ends in a token or in quit
-                    verdict = -1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
+                MRZ_WAIT_STORES();  // (the invalidate has completed)
+                S->ctl[2] = verdict;
             }
-            MRZ_WAIT_STORES();  // (the invalidate has completed)
-            S->ctl[2] = verdict;
+            MRZ_WAVE_SYNC();
+            // the state the last committer has handed on: one load instruction, a word per lane, from the L2
+            if (mrz_uni(S->ctl[2]) > 0 && lane < MRZ_H_N)
+                S->hand[lane] = __hip_atomic_load(&G->hand[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const int verdict = mrz_uni(S->ctl[2]);
@@ -309,18 +339,18 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 #ifdef MRZ_SEQ_PROFILE
         const int64_t turn_t0 = (int64_t)__builtin_amdgcn_s_memtime();
 #endif
-        L = G->L;
-        gseq = G->gseq;
-        gnw = G->gnw;
-        farm_hint = G->farm_hint;
-        const long long cur_epoch = G->epoch;
+        L = *(const mrz_lead *)&S->hand[MRZ_H_L];
+        gseq = S->hand[MRZ_H_GSEQ];
+        gnw = (int)S->hand[MRZ_H_GNW];
+        farm_hint = (int64_t)S->hand[MRZ_H_FARM];
+        const long long cur_epoch = (long long)S->hand[MRZ_H_EPOCH];
         if (cur_epoch != epoch || !have_prep || L.min_mask != p_min || L.tag_mask != p_tag) {
             // prepared under an older epoch (or not at all): once more, now that everything before it is committed
             epoch = cur_epoch;
-            base_word = G->base_word;
-            base_batch = G->base_batch;
-            base_pos = G->base_pos;
-            pw = G->pw;
+            base_word = (long long)S->hand[MRZ_H_BWORD];
+            base_batch = (long long)S->hand[MRZ_H_BBATCH];
+            base_pos = (long long)S->hand[MRZ_H_BPOS];
+            pw = (int)S->hand[MRZ_H_PW];
             snap = (unsigned)b;
             win_start = seg_start + (base_word + ((long long)b - base_batch) * pw) * 64;
             win_len = pw * 64;
@@ -377,11 +407,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                         if (!window_done)
                             new_pw = total > MRZ_W ? pw * 3 / 4 : pw / 2;  // too many: candidates, or bits to examine
                         else if (total < MRZ_W * 3 / 8 && pw < MRZ_W) {
-                            const int small = mrz_uni(G->small_run) + 1;
-                            if (lane == 0) G->small_run = small >= 4 ? 0 : small;
+                            const int small = mrz_uni((int)S->hand[MRZ_H_SMALL]) + 1;
+                            MRZ_WAVE_SYNC();
+                            if (lane == 0) S->hand[MRZ_H_SMALL] = (unsigned long long)(small >= 4 ? 0 : small);
                             if (small >= 4) new_pw = (int)((long long)pw * (MRZ_W * 3 / 4) / (total > 16 ? total : 16));
                         } else if (lane == 0)
-                            G->small_run = 0;
+                            S->hand[MRZ_H_SMALL] = 0;
                         if (new_pw > MRZ_W) new_pw = MRZ_W;
                         if (new_pw < 1 && new_pw != 0) new_pw = 1;
                         if (new_pw == pw) new_pw = 0;
@@ -406,11 +437,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                         if (verdict2 == 2) {
                             int64_t pos = L.p + 1;
                             if (pos < seg_start) pos = seg_start;
-                            G->epoch = cur_epoch + 1;
-                            G->base_word = (pos - seg_start) >> 6;
-                            G->base_pos = pos;
-                            G->base_batch = (long long)b + 1;
-                            G->pw = masks_moved ? mrz_words_per_batch(L.min_mask) : (new_pw > 0 ? new_pw : pw);
+                            S->hand[MRZ_H_EPOCH] = (unsigned long long)(cur_epoch + 1);
+                            S->hand[MRZ_H_BWORD] = (unsigned long long)((pos - seg_start) >> 6);
+                            S->hand[MRZ_H_BPOS] = (unsigned long long)pos;
+                            S->hand[MRZ_H_BBATCH] = b + 1;
+                            S->hand[MRZ_H_PW] =
+                                (unsigned long long)(masks_moved ? mrz_words_per_batch(L.min_mask) : (new_pw > 0 ? new_pw : pw));
                         }
                         S->ctl[3] = ((r.ok && rounds <= 2 * MRZ_W) ? 0 : 1) | (finish ? 2 : 0) | (verdict2 == 1 ? 4 : 0);
                         S->lead = L;
@@ -429,11 +461,16 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             }
         }
         // ---- hand the state on -----------------------------------------------------------------------------------
-        if (wave == 0 && lane == 0) {
-            G->L = L;
-            G->gseq = gseq;
-            G->gnw = gnw;
-            G->farm_hint = farm_hint;
+        if (wave == 0) {
+            // one store instruction, a word per lane
+            if (lane == 0) {
+                *(mrz_lead *)&S->hand[MRZ_H_L] = L;
+                S->hand[MRZ_H_GSEQ] = gseq;
+                S->hand[MRZ_H_GNW] = (unsigned long long)gnw;
+                S->hand[MRZ_H_FARM] = (unsigned long long)farm_hint;
+            }
+            MRZ_WAVE_SYNC();
+            if (lane < MRZ_H_N) __hip_atomic_store(&G->hand[lane], S->hand[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         MRZ_WAIT_STORES();  // every wave's table / log stores have reached the L2 ...
         __syncthreads();    // ... before the lane that passes the token on leaves this barrier
@@ -525,6 +562,13 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     return hipGetLastError();
 }
 
+#ifdef MRZ_DBG_HITS
+extern "C" int mrz_dbg_hits_set(unsigned *dev_ptr, long long n) {
+    int e = (int)hipMemcpyToSymbol(HIP_SYMBOL(mrz_dbg_hits), &dev_ptr, sizeof(dev_ptr));
+    if (!e) e = (int)hipMemcpyToSymbol(HIP_SYMBOL(mrz_dbg_n), &n, sizeof(n));
+    return e;
+}
+#endif
 extern "C" size_t mrz_sequencer_shared_size(void) { return sizeof(mrz_wide_shared); }
 extern "C" size_t mrz_sequencer_wlog_size(int64_t nslots) { return (size_t)((nslots >> MRZ_WLOG_SHIFT) + 1) * sizeof(unsigned); }
 

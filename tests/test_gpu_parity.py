@@ -84,6 +84,22 @@ def test_tar_like_mix(gpu_lib, oracle):
     _parity.check_chunk(gpu_lib, oracle, _util.tar_like(8 << 20, seed=5))
 
 
+def test_crowded_chains_run_the_entry_pool_dry(gpu_lib, oracle):
+    """A 997-byte period at level 7: every look-up finds max_chain_len tag-equal entries, so a 512-lane batch wants
+    7-8 k pool entries where the LDS pool holds 4 k; which lanes get chunks depends on the order of the atomics.  A lane
+    that got none must not store through a chunk id of an earlier batch (it once did: a fuzz find, hits counted as
+    misses in some runs only).  Several runs, several workgroup counts: every one must equal the oracle."""
+    data = _util.rep64k(4750705 // 997, seed=628395130, period=997)
+    import os
+    for wgs in ("1", "2", "3"):
+        os.environ["MRZ_SEQ_WGS"] = wgs
+        try:
+            for _ in range(3):
+                _parity.check_chunk(gpu_lib, oracle, data, level=7, victim_round=2)
+        finally:
+            del os.environ["MRZ_SEQ_WGS"]
+
+
 def test_stride_repeats_unlimited_window(gpu_lib, oracle):
     """BASELINE configs[3] shape, scaled: noise segments with planted repeats 1, 3 and 7 segments back, one chunk
     (-U).  Matches are a quarter segment long and reach back up to 7 segments."""
