@@ -35,7 +35,9 @@
 #include "mrz_seq_common.h"
 
 #define MRZ_W MRZ_SEQ_THREADS
-#define MRZ_POOL (2 * MRZ_W)          // chunks of 4 tag-equal entries: 8 entries per lane on average (a lane holds up to 16)
+#ifndef MRZ_POOL
+#define MRZ_POOL (2 * MRZ_W)  // chunks of 4 tag-equal entries: 8 entries per lane on average (a lane holds up to 16)
+#endif
 #define MRZ_PAIR_MAX (MRZ_POOL * 4)
 #define MRZ_BH_SIZE 2048              // block-hash entries (64-slot blocks written by this batch)
 #define MRZ_BH_WRITERS 5
@@ -215,6 +217,9 @@ __device__ __forceinline__ bool mrz_pool_put(mrz_wide_lds *S, int gl, int idx, i
         S->nchunk[gl] = (unsigned char)((idx >> 2) + 1);
     }
     const int c = S->chunk_id[gl][idx >> 2];
+#ifdef MRZ_EMU_LDS_PER_BLOCK
+    if (c >= MRZ_POOL) __builtin_trap();  // (test emulator: ids are poisoned at the start of a batch)
+#endif
     S->pool[c].e[idx & 3] = (unsigned long long)off | ((unsigned long long)(unsigned)slot << MRZ_OFF_BITS);
     return true;
 }
@@ -472,9 +477,13 @@ __device__ static void mrz_wide_walk(const mrz_cfg &C, mrz_wide_lds *S, bool go,
                             const int id = S->chunk_id[gl_o][idx >> 2];
                             if (id == 0xffff || (idx >> 2) >= S->nchunk[gl_o])  // (never handed out: the pool had run dry)
                                 bad = true;
-                            else
+                            else {
+#ifdef MRZ_EMU_LDS_PER_BLOCK
+                                if (id >= MRZ_POOL) __builtin_trap();
+#endif
                                 S->pool[id].e[idx & 3] =
                                     (unsigned long long)e.off | ((unsigned long long)(unsigned)slot << MRZ_OFF_BITS);
+                            }
                         }
                     }
                     if (__ballot(bad)) {
@@ -864,6 +873,10 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     }
     S->exec[tid] = 0;
     S->nchunk[tid] = 0;
+#ifdef MRZ_EMU_LDS_PER_BLOCK
+    // (test emulator: a chunk id left over from an earlier batch must never be used -- make such a use fault)
+    for (int k = 0; k < 4; k++) S->chunk_id[tid][k] = (unsigned short)0xffff;
+#endif
     S->supp_w[tid] = (unsigned short)MRZ_W;
     S->supp_w2[tid] = (unsigned short)MRZ_W;
     const int64_t cw_base = 0;  // the cull window is the pre-commit step's business
