@@ -64,16 +64,14 @@ struct mrz_chunk4 {
 };
 
 struct mrz_wide_lds {
-    mrz_lead Lp;          // the leader's state, published by wave 0 before a wide step
     int ctl[16];          // control words between wave 0 and the others
-    int cmd;              // bumped by wave 0 for every command; the other waves wait on it
     int nb, total;        // lanes of the prepared batch; candidates in its bitmap window
     int bulk_y, bulk_a1, bulk_a2, bulk_end;  // bulk commit done by the pre-commit step: lanes [first_live, bulk_y), totals
     int first_live;       // first lane behind L.p (where the commit starts or resumes)
     int rank0;            // culls of this batch's cull window used up before that lane
-    long long snap64[10];
+    long long snap64[10];  // the snapshot a preparation works from (token, epoch, window base, masks)
     mrz_lead lead;        // the matcher's state after a commit, for the waves that did not run it
-    unsigned long long hand[32];  // the hand-over block of mrz_wide_shared: loaded at a turn, stored at its end  // the snapshot a preparation works from (token, epoch, window base, masks)
+    unsigned long long hand[32];  // the hand-over block of mrz_wide_shared: loaded at a turn, stored at its end
     int64_t prep_min_mask, prep_tag_mask;  // the masks the batch was prepared under
     int64_t cw_base, w_end, floor_prep;
     int64_t adv_to, scan_last;  // see mrz_wide_prep

@@ -5,21 +5,23 @@
 // in-place culling without tombstones :305-328, the process-lifetime victim_round :259), so it has to be
 // replayed in position order to stay bit-exact.  What the GPU changes is the width of every step.
 //
-// Grid: block 0 is the SEQUENCER workgroup (MRZ_SEQ_WAVES waves, 512 threads), blocks 1.. are the helper
-// workgroups of the compare farm (mrz_seq_common.h).  The sequencer alternates between two engines:
+// Grid: blocks 0, 8, 16, ... (up to MRZ_SEQ_WGS of them; one XCD under round-robin placement, checked at run time)
+// are SEQUENCER workgroups of MRZ_SEQ_WAVES waves (512 threads); the other blocks are the helper workgroups of the
+// compare farm (mrz_seq_common.h).  The sequencer workgroups run the WIDE BATCH ENGINE (mrz_seq_wide.h) and take
+// turns:
 //
-//   * the WIDE BATCH ENGINE (mrz_seq_wide.h): the next 512 candidates at once, one lane each -- probe walks
-//     and 64-byte match probes speculatively against the table as it stands, then an in-order commit in
-//     segments with workgroup-wide scans for the sequential quantities, the lazy-match fold as a prefix
-//     maximum, emissions handled inside the batch.  This is what dense candidates (text, noise) run on;
-//   * the COOPERATIVE PATH (mrz_seq_candidate): one candidate, wave 0 on its chain 64 slots per step, any
-//     chain / match length (striped 4 KiB rounds, compare farm), cascades, evictions, sweep wrap, mask
-//     promotion.  The wide engine hands over every lane it cannot prove; streams that are one long match
-//     after another (every look-up finds max_chain_len entries tens of KiB long) run here directly,
-//     chosen by a small predictor.
+//   * batches are fixed windows of positions; a workgroup PREPARES its batch -- probe walks, conflicts inside the
+//     batch, overlay walks, 64-byte match probes, all read-only -- while the batches before it are being committed;
+//   * at its TURN (a token in device memory) it loads the matcher state, brings the prepared lanes up to date
+//     (lanes a match has covered since, table blocks written since: the write log; the cull window), commits in
+//     order -- clean stretches by all waves at once, the rest by wave 0 in windows of 64 lanes with the lazy-match
+//     fold as a prefix maximum -- and hands state and token on;
+//   * a lane the batch cannot prove (stale, long chain, deep cascade, sweep wrap, mask promotion) goes through the
+//     COOPERATIVE PATH (mrz_seq_candidate): one candidate, wave 0 on its chain 64 slots per step, any chain / match
+//     length (striped 4 KiB rounds, compare farm).
 //
-// Wave 0 owns the matcher state (wave-uniform, in SGPRs) and decides the mode; the other waves follow through
-// LDS control words.  Emitted matches go to an event list; record encoding, literal gathering and the CRC are
+// Streams that are one long match after another run on the narrow engine instead (mrz_seq_narrow.hip, picked per
+// segment by the host).  Emitted matches go to an event list; record encoding, literal gathering and the CRC are
 // separate parallel kernels.
 //
 // Bound: latency -- a chain of dependent table probes, data probes and cross-CU hand-offs; DESIGN.md 4.2.
