@@ -45,11 +45,15 @@
 #ifndef MRZ_OV_ROUNDS
 #define MRZ_OV_ROUNDS 3  // overlay rounds of a preparation (a repaired writer makes its readers repairable)
 #endif
-#define MRZ_CW_WORDS 32               // cull window: 32 x 64 slots ahead of tag_clean_ptr
+#ifndef MRZ_CW_WORDS
+#define MRZ_CW_WORDS 32  // cull window: 32 x 64 slots ahead of tag_clean_ptr
+#endif
 #define MRZ_NW_MAX 192
 #define MRZ_XW_MAX 48
 #ifndef MRZ_BULK_MIN
-#define MRZ_BULK_MIN 96              // leading lanes worth a workgroup-wide bulk commit
+#ifndef MRZ_BULK_MIN
+#define MRZ_BULK_MIN 96  // leading lanes worth a workgroup-wide bulk commit
+#endif
 #endif
 #ifndef MRZ_WR_MAX
 #define MRZ_WR_MAX 3   // earlier writers of this batch an overlay walk can take into account

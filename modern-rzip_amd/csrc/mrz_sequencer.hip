@@ -47,6 +47,9 @@ extern __device__ unsigned *mrz_dbg_hits;
 #ifndef MRZ_SEQ_WGS
 #define MRZ_SEQ_WGS 4
 #endif
+#ifndef MRZ_FILL_NUM
+#define MRZ_FILL_NUM 14  // a window is sized for 14/16 of the lanes
+#endif
 #define MRZ_TURN_SPIN_LIMIT (1ll << 27)
 
 // words of mrz_wide_shared.hand: the matcher state (mrz_lead, 16 words) and what goes with it
@@ -90,7 +93,7 @@ static_assert(offsetof(mrz_wide_shared, hand) == 128, "the hand-over block has i
 __device__ __forceinline__ int mrz_words_per_batch(int64_t min_mask) {
     // candidates are 2^-k of the positions (k mask bits): aim at 7/8 of the lanes, whole bitmap words
     const int k = __popcll((unsigned long long)min_mask);
-    long long pos = (long long)(MRZ_W * 7 / 8) << (k < 20 ? k : 20);
+    long long pos = (long long)(MRZ_W * MRZ_FILL_NUM / 16) << (k < 20 ? k : 20);
     long long wds = pos / 64;
     if (wds > MRZ_W) wds = MRZ_W;
     return (int)(wds < 1 ? 1 : wds);
@@ -473,9 +476,20 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             }
             MRZ_WAVE_SYNC();
             if (lane < MRZ_H_N) __hip_atomic_store(&G->hand[lane], S->hand[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... and the token right behind it.  Every table / log store of this turn has completed already: the
+            // bulk steps and the commit end in a wait for their own (MRZ_STORES_DONE), and the other waves have stored
+            // nothing since; what is waited for here are the state words above.  The XCD's L2 need not be written back
+            // for a reader on the same XCD.
+            if (ok && !finish) {
+                MRZ_WAIT_STORES();
+                if (lane == 0) __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        MRZ_WAIT_STORES();  // every wave's table / log stores have reached the L2 ...
-        __syncthreads();    // ... before the lane that passes the token on leaves this barrier
+#ifdef MRZ_SEQ_PROFILE
+        stat[MRZ_ST_T_TURNWORK] += (int64_t)__builtin_amdgcn_s_memtime() - turn_t0;
+#endif
+        MRZ_WAIT_STORES();
+        __syncthreads();
         if (!ok || finish) {
             if (tid == 0) {
                 // the end of the launch: publish the state for the next segment's launch, release everybody
@@ -505,17 +519,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             }
             break;
         }
-        if (tid == 0) {
-            // every wave's stores have reached the L2 (each waited for its own before the barrier above; this lane's
-            // state stores are waited for here); the XCD's L2 need not be written back for a reader on the same XCD
-            MRZ_WAIT_STORES();
-            __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#ifdef MRZ_SEQ_PROFILE
-        stat[MRZ_ST_T_TURNWORK] += (int64_t)__builtin_amdgcn_s_memtime() - turn_t0;
-#endif
         b += (unsigned long long)n_act;
-        __syncthreads();
     }
 #ifdef MRZ_SEQ_STATS
     if (tid == 0)
