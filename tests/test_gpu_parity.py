@@ -84,6 +84,16 @@ def test_tar_like_mix(gpu_lib, oracle):
     _parity.check_chunk(gpu_lib, oracle, _util.tar_like(8 << 20, seed=5))
 
 
+@pytest.mark.parametrize("wgs", ["1", "2", "4"])
+def test_sequencer_workgroup_counts(gpu_lib, oracle, wgs, monkeypatch):
+    """The wide engine with 1, 2 and 4 sequencer workgroups taking turns (3 is the default every other test runs with):
+    same streams, counters and table as the oracle, on text, noise (culling, mask promotion) and the tar mix."""
+    monkeypatch.setenv("MRZ_SEQ_WGS", wgs)
+    _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(6 << 20, seed=11), table=True)
+    _parity.check_chunk(gpu_lib, oracle, _util.xorshift_noise(24 << 20, seed=12), table=True)
+    _parity.check_chunk(gpu_lib, oracle, _util.tar_like(12 << 20, seed=13), level=4)
+
+
 def test_crowded_chains_run_the_entry_pool_dry(gpu_lib, oracle):
     """A 997-byte period at level 7: every look-up finds max_chain_len tag-equal entries, so a 512-lane batch wants
     7-8 k pool entries where the LDS pool holds 4 k; which lanes get chunks depends on the order of the atomics.  A lane
