@@ -127,7 +127,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     const bool is_seq = (bx % 8 == 0) && (bx / 8 < wgs);
 #if MRZ_HELPER_WGS > 0
     if (!is_seq) {
-        mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
+        if (a.gmailbox) mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);  // (no mailbox: a launch without a farm)
         return;
     }
 #else

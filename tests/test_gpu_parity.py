@@ -139,6 +139,16 @@ def test_small_or_no_compare_farm(farm_wgs):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("wgs", ["2", "3"])
+def test_no_farm_mailbox_with_several_sequencer_workgroups(gpu_lib, oracle, wgs, monkeypatch):
+    """MRZ_NO_HELPER_WGS=1: no mailbox is allocated, yet the grid still has blocks between the sequencer workgroups
+    (0, 8, 16): they must leave at once instead of taking a farm ticket from a null mailbox."""
+    monkeypatch.setenv("MRZ_NO_HELPER_WGS", "1")
+    monkeypatch.setenv("MRZ_SEQ_WGS", wgs)
+    _parity.check_chunk(gpu_lib, oracle, _util.rep64k(160, seed=21))
+    _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(3 << 20, seed=5))
+
+
 def test_segment_boundaries(gpu_lib, oracle):
     # > 16 Mi positions: the chunk spans two tag-scan segments, with matches crossing the seam
     blk = _util.zipf_text(9 << 20, seed=31)
