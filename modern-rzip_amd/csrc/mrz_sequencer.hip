@@ -365,6 +365,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                                              L.min_mask, L.tag_mask, tid, lane, wave, stat);
         }
         bool finish = false;
+        int passed_on = 0;  // the committing wave has handed state and token on already
         if (win_start > lim) {
             // the segment is done: nothing but the end is left
             if (L.p < lim) L.p = lim;
@@ -384,12 +385,91 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 r.stop_batch = false;
                 r.rebulk = false;
                 for (;;) {
-                    // wave 0 commits; when it finds a long clean stretch behind a hand-over it has all waves commit that
+                    // wave 0 commits; when it finds a long clean stretch behind a hand-over it has all waves commit that;
+                    // else it decides how the turn ends and -- if it ends here -- hands state and token on at once, before
+                    // the barrier the other waves are waiting at
                     if (wave == 0) {
                         mrz_wide_commit(C, L, S, wlog, (unsigned)b, lane, stat, &r);
-                        if (lane == 0) {
-                            S->ctl[4] = r.rebulk ? 1 : 0;
-                            if (r.rebulk) S->lead = L;
+                        if (r.rebulk) {
+                            if (lane == 0) {
+                                S->ctl[4] = 1;
+                                S->lead = L;
+                            }
+                        } else {
+                            const int64_t w_end = mrz_uni64(S->w_end), adv_to = mrz_uni64(S->adv_to);
+                            const int total = mrz_uni(S->total);
+                            const bool masks_moved = L.min_mask != mrz_uni64(S->prep_min_mask) || L.tag_mask != mrz_uni64(S->prep_tag_mask);
+                            const bool all_lanes = r.whole && !r.stop_batch;
+                            if (all_lanes && adv_to > L.p) L.p = adv_to;  // no candidate is left up to there
+                            const bool window_done = all_lanes && adv_to == w_end;
+                            const bool far = L.p > w_end + (int64_t)n_act * win_len;
+                            // the window size follows what the windows turn out to hold (the bitmap's density is not the mask's)
+                            int new_pw = 0;
+                            if (rounds == 0 && all_lanes) {
+                                if (!window_done)
+                                    new_pw = total > MRZ_W ? pw * 3 / 4 : pw / 2;  // too many: candidates, or bits to examine
+                                else if (total < MRZ_W * 3 / 8 && pw < MRZ_W) {
+                                    const int small = mrz_uni((int)S->hand[MRZ_H_SMALL]) + 1;
+                                    MRZ_WAVE_SYNC();
+                                    if (lane == 0) S->hand[MRZ_H_SMALL] = (unsigned long long)(small >= 4 ? 0 : small);
+                                    if (small >= 4) new_pw = (int)((long long)pw * (MRZ_W * 3 / 4) / (total > 16 ? total : 16));
+                                } else if (lane == 0)
+                                    S->hand[MRZ_H_SMALL] = 0;
+                                if (new_pw > MRZ_W) new_pw = MRZ_W;
+                                if (new_pw < 1 && new_pw != 0) new_pw = 1;
+                                if (new_pw == pw) new_pw = 0;
+                            }
+                            int verdict2 = 0;  // 0: pass the token on; 1: go on inside this window; 2: new epoch
+                            if (!r.ok || rounds > 2 * MRZ_W)
+                                verdict2 = 0;
+                            else if (masks_moved || far || L.p + 1 < win_start || new_pw > 0)
+                                verdict2 = 2;
+                            else if (window_done || L.p >= w_end)
+                                verdict2 = 0;
+                            else
+                                verdict2 = 1;
+                            if (L.p >= lim) {
+                                finish = true;
+                                if (verdict2 == 1) verdict2 = 0;
+                            }
+                            ST_ADD(MRZ_ST_E_MORE, (all_lanes && !window_done) ? 1 : 0);
+                            ST_ADD(MRZ_ST_RESET, verdict2 == 2 ? 1 : 0);
+                            ST_ADD(MRZ_ST_REPREP, verdict2 == 1 ? 1 : 0);
+                            if (lane == 0) {
+                                if (verdict2 == 2) {
+                                    int64_t pos = L.p + 1;
+                                    if (pos < seg_start) pos = seg_start;
+                                    S->hand[MRZ_H_EPOCH] = (unsigned long long)(cur_epoch + 1);
+                                    S->hand[MRZ_H_BWORD] = (unsigned long long)((pos - seg_start) >> 6);
+                                    S->hand[MRZ_H_BPOS] = (unsigned long long)pos;
+                                    S->hand[MRZ_H_BBATCH] = b + 1;
+                                    S->hand[MRZ_H_PW] =
+                                        (unsigned long long)(masks_moved ? mrz_words_per_batch(L.min_mask) : (new_pw > 0 ? new_pw : pw));
+                                }
+                                S->ctl[3] = ((r.ok && rounds <= 2 * MRZ_W) ? 0 : 1) | (finish ? 2 : 0) | (verdict2 == 1 ? 4 : 0);
+                                S->lead = L;
+                            }
+                            MRZ_WAVE_SYNC();
+                            const int fl0 = mrz_uni(S->ctl[3]);
+                            int passed = 0;
+                            if (fl0 == 0) {  // the turn ends here, and neither the launch nor anything else does
+                                if (lane == 0) {
+                                    *(mrz_lead *)&S->hand[MRZ_H_L] = L;
+                                    S->hand[MRZ_H_GSEQ] = gseq;
+                                    S->hand[MRZ_H_GNW] = (unsigned long long)gnw;
+                                    S->hand[MRZ_H_FARM] = (unsigned long long)farm_hint;
+                                }
+                                MRZ_WAVE_SYNC();
+                                if (lane < MRZ_H_N)
+                                    __hip_atomic_store(&G->hand[lane], S->hand[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                MRZ_WAIT_STORES();
+                                if (lane == 0) __hip_atomic_store(&G->token, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                passed = 1;
+                            }
+                            if (lane == 0) {
+                                S->ctl[4] = 0;
+                                S->ctl[7] = passed;
+                            }
                         }
                     }
                     __syncthreads();
@@ -398,63 +478,8 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                     mrz_wide_bulk<MRZ_SEQ_WAVES>(C, L, S, wlog, (unsigned)b, mrz_uni(S->first_live), mrz_uni(S->rank0), true, tid,
                                                  lane, wave);
                 }
-                if (wave == 0) {
-                    const int64_t w_end = mrz_uni64(S->w_end), adv_to = mrz_uni64(S->adv_to);
-                    const int total = mrz_uni(S->total);
-                    const bool masks_moved = L.min_mask != mrz_uni64(S->prep_min_mask) || L.tag_mask != mrz_uni64(S->prep_tag_mask);
-                    const bool all_lanes = r.whole && !r.stop_batch;
-                    if (all_lanes && adv_to > L.p) L.p = adv_to;  // no candidate is left up to there
-                    const bool window_done = all_lanes && adv_to == w_end;
-                    const bool far = L.p > w_end + (int64_t)n_act * win_len;
-                    // the window size follows what the windows turn out to hold (the bitmap's density is not the mask's)
-                    int new_pw = 0;
-                    if (rounds == 0 && all_lanes) {
-                        if (!window_done)
-                            new_pw = total > MRZ_W ? pw * 3 / 4 : pw / 2;  // too many: candidates, or bits to examine
-                        else if (total < MRZ_W * 3 / 8 && pw < MRZ_W) {
-                            const int small = mrz_uni((int)S->hand[MRZ_H_SMALL]) + 1;
-                            MRZ_WAVE_SYNC();
-                            if (lane == 0) S->hand[MRZ_H_SMALL] = (unsigned long long)(small >= 4 ? 0 : small);
-                            if (small >= 4) new_pw = (int)((long long)pw * (MRZ_W * 3 / 4) / (total > 16 ? total : 16));
-                        } else if (lane == 0)
-                            S->hand[MRZ_H_SMALL] = 0;
-                        if (new_pw > MRZ_W) new_pw = MRZ_W;
-                        if (new_pw < 1 && new_pw != 0) new_pw = 1;
-                        if (new_pw == pw) new_pw = 0;
-                    }
-                    int verdict2 = 0;  // 0: pass the token on; 1: go on inside this window; 2: new epoch
-                    if (!r.ok || rounds > 2 * MRZ_W)
-                        verdict2 = 0;
-                    else if (masks_moved || far || L.p + 1 < win_start || new_pw > 0)
-                        verdict2 = 2;
-                    else if (window_done || L.p >= w_end)
-                        verdict2 = 0;
-                    else
-                        verdict2 = 1;
-                    if (L.p >= lim) {
-                        finish = true;
-                        if (verdict2 == 1) verdict2 = 0;
-                    }
-                    ST_ADD(MRZ_ST_E_MORE, (all_lanes && !window_done) ? 1 : 0);
-                    ST_ADD(MRZ_ST_RESET, verdict2 == 2 ? 1 : 0);
-                    ST_ADD(MRZ_ST_REPREP, verdict2 == 1 ? 1 : 0);
-                    if (lane == 0) {
-                        if (verdict2 == 2) {
-                            int64_t pos = L.p + 1;
-                            if (pos < seg_start) pos = seg_start;
-                            S->hand[MRZ_H_EPOCH] = (unsigned long long)(cur_epoch + 1);
-                            S->hand[MRZ_H_BWORD] = (unsigned long long)((pos - seg_start) >> 6);
-                            S->hand[MRZ_H_BPOS] = (unsigned long long)pos;
-                            S->hand[MRZ_H_BBATCH] = b + 1;
-                            S->hand[MRZ_H_PW] =
-                                (unsigned long long)(masks_moved ? mrz_words_per_batch(L.min_mask) : (new_pw > 0 ? new_pw : pw));
-                        }
-                        S->ctl[3] = ((r.ok && rounds <= 2 * MRZ_W) ? 0 : 1) | (finish ? 2 : 0) | (verdict2 == 1 ? 4 : 0);
-                        S->lead = L;
-                    }
-                }
-                __syncthreads();
                 const int fl = mrz_uni(S->ctl[3]);
+                passed_on = mrz_uni(S->ctl[7]);
                 if (fl & 1) ok = false;
                 finish = (fl & 2) != 0;
                 if (!(fl & 4)) break;
@@ -465,8 +490,8 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                                              L.min_mask, L.tag_mask, tid, lane, wave, stat);
             }
         }
-        // ---- hand the state on -----------------------------------------------------------------------------------
-        if (wave == 0) {
+        // ---- hand the state on (unless the committing wave has done so already) -----------------------------------
+        if (wave == 0 && !passed_on) {
             // one store instruction, a word per lane
             if (lane == 0) {
                 *(mrz_lead *)&S->hand[MRZ_H_L] = L;
