@@ -1794,8 +1794,34 @@ __device__ static void mrz_wide_commit(const mrz_cfg &C, mrz_lead &L, mrz_wide_l
                     const bool inwin = lane < nwx && cw_len > 0 && S->coop.pend_h[lane] >= cw_base &&
                                        S->coop.pend_h[lane] < cw_base + cw_len;
                     if (__ballot(inwin)) {
-                        stop_batch = true;
+                        // A write into the cull window changes which entries the sweep finds: the window's mask is
+                        // brought up to date (ahead of what the sweep has passed -- behind it nothing matters any more,
+                        // and the ranks already used must keep their meaning), counts and list are laid out again.
                         ST_ADD(MRZ_ST_E_INWIN, 1);
+                        const int64_t passed = cw_used > 0 ? (int64_t)mrz_cw_slot(S, cw_base, cw_used - 1) : cw_base - 1;
+                        MRZ_WAVE_SYNC();
+                        for (int k = 0; k < nwx; k++) {
+                            const int64_t X = mrz_uni64(S->coop.pend_h[k]);
+                            if (X < cw_base || X >= cw_base + cw_len || X <= passed) continue;
+                            const int64_t tX = mrz_uni64(S->coop.pend_t[k]);
+                            const bool failing = (tX & better) != better;  // (the slot now holds an entry)
+                            if (lane == 0) {
+                                const int bit = (int)(X - cw_base);
+                                const mrz_u64 m = 1ull << (bit & 63);
+                                S->cw[bit >> 6] = failing ? (S->cw[bit >> 6] | m) : (S->cw[bit >> 6] & ~m);
+                            }
+                            MRZ_WAVE_SYNC();
+                        }
+                        {
+                            const int c = lane < MRZ_CW_WORDS ? __popcll(S->cw[lane]) : 0;
+                            const int ci = mrz_wave_incl_sum(c, lane);
+                            if (lane < MRZ_CW_WORDS) S->cwcum[lane + 1] = ci;
+                            MRZ_WAVE_SYNC();
+                            const int tot = S->cwcum[MRZ_CW_WORDS];
+                            for (int r = lane; r < MRZ_W && r < tot; r += 64) S->cw_list[r] = mrz_cw_slot_search(S, cw_base, r);
+                            MRZ_WAVE_SYNC();
+                        }
+                        // (the ranks used so far lie behind `passed`: their bits were not touched)
                     }
                     nx += nwx + (cullx >= 0 ? 1 : 0);
                     if (lane == 0) S->xw_n = nx;
