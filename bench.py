@@ -287,24 +287,35 @@ def main():
 
 
 def window_mode(args, m, workloads, lib, dist, rank, world, dev_index):
-    """ONE window over the ranks (BASELINE configs[3], scaled to --gib): S4 stride stream, range-sharded tag scan, tags
-    to rank 0 (send/recv over RCCL or gloo), exact matcher on rank 0."""
+    """ONE window over the ranks (BASELINE configs[3], scaled to --gib): S4 stride stream; every rank runs the front end
+    over the stretches of its byte range and ships compacted candidate records to rank 0 (send/recv: RCCL moves device
+    tensors GPU to GPU; gloo takes the host path), the exact matcher runs on rank 0."""
     import torch
     from modern_rzip_amd import shard
-    segp = 16 << 20
-    seg_bytes = max(int(args.gib * GIB) // 16 // segp, 1) * segp
-    win = workloads.stride_stream(16, seg_bytes, seed=99)  # the same bytes on every rank (seeded generator)
-    total = len(win)
-    ranges = shard.segment_ranges(total, world, segp)
+    seg_bytes = max(int(args.gib * GIB) // 16 // 4096, 1) * 4096
+    total = 16 * seg_bytes
+    dev = torch.device("cuda", dev_index)
+    use_dev = args.dist_backend == "nccl"
+    ranges = shard.window_ranges(total, world)
     off, size = ranges[rank]
-    mine = win[off:off + size + 48]
+    # the same bytes on every rank (seeded generator on the device); a rank keeps its range (+ halo), rank 0 the window
+    win = workloads.stride_stream_device(16, seg_bytes, dev, seed=99)
+    mine = win[off:off + size + 48].clone()
+    window = win if rank == 0 else None
+    if rank != 0:
+        del win
+        torch.cuda.empty_cache()
     ctx = m.RzipContext(level=args.level, max_chunk=total if rank == 0 else 0, device=dev_index, lib=lib)
     times = []
     res = None
     for it in range(args.warmup + args.steps):
         dist.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = shard.rzip_chunk_window(ctx, mine, off, total, rank, world, dist, segp, gather_bytes=(it == 0))
+        out = shard.rzip_chunk_window(ctx, mine if use_dev else bytes(mine.cpu().numpy().tobytes()), off, total, rank, world,
+                                      dist, window=window if rank == 0 else b"", device=dev if use_dev else None,
+                                      cap=8 << 20, ranges=ranges)
+        torch.cuda.synchronize()
         dist.barrier()
         if it >= args.warmup:
             times.append(time.perf_counter() - t0)
@@ -317,8 +328,10 @@ def window_mode(args, m, workloads, lib, dist, rank, world, dev_index):
                           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                           "config": {"workload": f"stride-{total / GIB:g}G: ONE window (-U) of noise segments with planted "
-                                                 f"repeats (BASELINE configs[3], scaled), range-sharded over the GPUs",
-                                     "mode": "window", "level": args.level, "window_bytes": total},
+                                                 f"repeats (BASELINE configs[3], scaled), front end range-sharded over the "
+                                                 f"ranks, candidate records to rank 0 over {args.dist_backend}",
+                                     "mode": "window", "level": args.level, "window_bytes": total,
+                                     "served": getattr(ctx, "window_served", None)},
                           "result": {"s0_len": res.s0_len, "s1_len": res.s1_len, "matches": res.stats.matches}}), flush=True)
     ctx.close()
     dist.destroy_process_group()

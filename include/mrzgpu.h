@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRZ_ABI_VERSION 2
+#define MRZ_ABI_VERSION 3
 
 enum {
     MRZ_OK = 0,
@@ -105,8 +105,8 @@ int mrz_set_profiling(mrz_ctx *ctx, int enable);
  * MRZ_FARM_WGS environment variable).  Several ctxs (or processes) sharing one GPU should split the CUs
  * between them, e.g. 224 / number of streams; 0 = no helpers (everything on the sequencer's own CU);
  * negative = back to the default.  Independent streams then overlap on the device: measured 3.1x aggregate
- * for 4 streams.  (In one process this needs GPU_MAX_HW_QUEUES >= 2 x ctxs when the HIP runtime initialises;
- * the library sets 8 at load time unless the variable is already set.) */
+ * for 4 streams.  (In one process this needs the HIP runtime to open enough hardware queues: the HOST PROGRAM has to
+ * export GPU_MAX_HW_QUEUES >= 2 x ctxs before the runtime initialises -- the library does not touch the environment.) */
 int mrz_set_farm_helpers(mrz_ctx *ctx, int n);
 int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out);
 
@@ -126,32 +126,55 @@ int mrz_set_progress(mrz_ctx *ctx, mrz_progress_fn fn, void *user);
 /* copies matches [first, first + count) of the chunk in flight (or of the last chunk) to host memory */
 int mrz_fetch_events(mrz_ctx *ctx, int64_t first, int64_t count, mrz_match *host_dst);
 
-/* ---- one window over several GPUs (second row; BASELINE configs[3]) --------------------------
- * What shards inside ONE chunk is the front end: every rank owns a contiguous byte range of the window (plus a
- * 30-byte halo) and computes the tags of its positions (single_full_tag / next_tag, src/rzip.c:330-358) and the
- * candidate bitmap for the mask the matcher has reached (:573); the exact matcher itself stays on one rank, which
- * takes the segments' tags from their owners instead of scanning them.
+/* ---- the front end's candidate list; one window over several GPUs (second row; BASELINE configs[3]) ----
+ * The tag of every position (single_full_tag / next_tag, src/rzip.c:330-358) is computed by a parallel front end, and
+ * what the exact matcher consumes is the position-ordered list of the CANDIDATES -- the positions whose tag passes the
+ * matcher's minimum_tag_mask (:573), 16 bytes {position, tag} each -- of one stretch of the chunk after another.
+ * A front-end pass looks at no more than `segment positions` positions and stops where its list is full (`candidate
+ * capacity` entries); the next pass goes on from there.
  *
- * mrz_window_scan (any rank): tags and bitmap of positions [seg_start, seg_start + seg_len) of a chunk of chunk_n
- * bytes, given the rank's bytes [range_start, range_start + range_len) -- which must reach 48 bytes past the
- * segment's last position (30 for the tags, the rest because the kernel loads 16-byte pieces) or to the end of the
- * chunk; seg_len a multiple of 4096 unless the segment is the chunk's last.  min_mask: the matcher's minimum_tag_mask as last heard of
- * (an older, looser mask only makes the bitmap a superset, which the matcher re-checks); p_done: positions at or
- * before it need no tags.  tags_out: seg_len x int64, bitmap_out: ceil(seg_len / 64) x uint64, host memory.
+ * What shards inside ONE chunk is this front end: every rank owns a contiguous byte range of the window (plus a
+ * 48-byte halo) and scans the stretches that lie in it; the exact matcher itself stays on one rank, which takes the
+ * lists from their owners instead of scanning.
  *
- * mrz_set_tag_provider (the matcher's rank): mrz_rzip_chunk then calls `fn` for every segment it is about to
- * sequence instead of scanning it; `fn` has to fill the two device buffers (seg_len x int64 tags, seg_len / 64
- * words of bitmap; e.g. hipMemcpyAsync on `stream`, or a blocking copy) and return 0.  fn = NULL: scan locally.
- * mrz_set_segment_positions: positions per segment launch (a multiple of 4096, at most the default of 16 Mi). */
+ * mrz_window_scan (any rank): one pass over positions [seg_start, seg_start + max_span) of a chunk of chunk_n bytes,
+ * given the rank's bytes [range_start, range_start + range_len) -- which must reach 48 bytes past the last position
+ * looked at (30 for the tags, the rest because the kernels load 16-byte pieces) or to the end of the chunk; seg_start
+ * and max_span multiples of 4096.  min_mask: the matcher's minimum_tag_mask as last heard of (an older, looser mask
+ * only makes the list a superset, which the matcher re-checks); p_done: positions at or before it are left out.
+ * Outputs, in host or device memory per out_where: cand_out, room for `cap` entries; tile_off_out, max_span / 4096 + 1
+ * ints (list offset of every 4096-position tile); bitmap_out, max_span / 8 bytes (1 pass bit per position).
+ * *scan_next: where the pass stopped (the next one starts there; a multiple of 4096); *n_cand: entries written.
+ *
+ * mrz_set_cand_provider (the matcher's rank): mrz_rzip_chunk then calls `fn` for every stretch it is about to
+ * sequence instead of scanning it; `fn` has to fill the three DEVICE buffers (as mrz_window_scan lays them out; e.g.
+ * by hipMemcpyAsync on `stream`, by a peer copy, or mrz_copy_to_device), set *scan_next and *n_cand, and return 0.
+ * fn = NULL: scan locally. */
+typedef struct {
+    int64_t pos; /* position in the chunk */
+    int64_t tag; /* its tag (a 47-bit value, typedef i64 tag, include/mrzip_private.h:375) */
+} mrz_candidate;
 int mrz_window_scan(mrz_ctx *ctx, const void *range_bytes, int64_t range_len, int where, int64_t range_start,
-                    int64_t chunk_n, int64_t seg_start, int64_t seg_len, int64_t min_mask, int64_t p_done,
-                    int64_t *tags_out, uint64_t *bitmap_out);
-typedef int (*mrz_tag_provider_fn)(void *user, int64_t seg_index, int64_t seg_start, int64_t seg_len, int64_t min_mask,
-                                   int64_t p_done, int64_t *d_tags, uint64_t *d_bitmap, void *stream);
-int mrz_set_tag_provider(mrz_ctx *ctx, mrz_tag_provider_fn fn, void *user);
+                    int64_t chunk_n, int64_t seg_start, int64_t max_span, int64_t min_mask, int64_t p_done, int64_t cap,
+                    mrz_candidate *cand_out, int32_t *tile_off_out, void *bitmap_out, int out_where, int64_t *scan_next,
+                    int64_t *n_cand);
+typedef int (*mrz_cand_provider_fn)(void *user, int64_t seg_start, int64_t max_span, int64_t min_mask, int64_t p_done,
+                                    int64_t cap, mrz_candidate *d_cand, int32_t *d_tile_off, void *d_bitmap,
+                                    int64_t *scan_next, int64_t *n_cand, void *stream);
+int mrz_set_cand_provider(mrz_ctx *ctx, mrz_cand_provider_fn fn, void *user);
+/* positions a front-end pass looks at, at most (a multiple of 4096; default 2^30), and entries its list holds (>= 4096;
+ * default 8 Mi = 128 MiB) */
 int mrz_set_segment_positions(mrz_ctx *ctx, int64_t positions);
-/* host -> device copy on the ctx stream (what a tag provider without a HIP runtime of its own fills the buffers with) */
+int mrz_set_candidate_capacity(mrz_ctx *ctx, int64_t entries);
+/* host -> device / device -> device copy on the ctx stream (what a provider without a HIP runtime of its own fills the
+ * buffers with); returns when the source may be reused */
 int mrz_copy_to_device(mrz_ctx *ctx, void *dst_device, const void *src_host, int64_t n);
+int mrz_copy_device(mrz_ctx *ctx, void *dst_device, const void *src_device, int64_t n);
+/* Which of the GPU's 8 XCDs carries this ctx's sequencer workgroups (0..7; default 0): block index mod 8 under the
+ * round-robin placement of workgroups.  The exact matcher of one chunk is one dependency chain on one XCD; ctxs that run
+ * concurrently (independent streams, chunks of one file) should get different values so that each has an XCD's
+ * L2 and CUs to itself. */
+int mrz_set_xcd(mrz_ctx *ctx, int xcd);
 
 /* ---- the rzip stage ---------------------------------------------------- */
 

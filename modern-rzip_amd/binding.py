@@ -34,9 +34,11 @@ class Timings(ctypes.Structure):
                 ("n_narrow", ctypes.c_int32)]
 
 
-# mrz_tag_provider_fn (include/mrzgpu.h)
-TAG_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
-                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+# mrz_cand_provider_fn (include/mrzgpu.h)
+CAND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p)
+TILE = 4096  # positions per front-end tile
 
 
 class RsReport(ctypes.Structure):
@@ -97,10 +99,14 @@ def load_library(path=None):
     if hasattr(lib, "mrz_rs_decode"):
         lib.mrz_rs_decode.argtypes = [vp, vp, i64, ci, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(RsReport)]
     if hasattr(lib, "mrz_window_scan"):
-        lib.mrz_window_scan.argtypes = [vp, vp, i64, ci, i64, i64, i64, i64, i64, i64, vp, vp]
-        lib.mrz_set_tag_provider.argtypes = [vp, TAG_FN, vp]
+        i64p = ctypes.POINTER(i64)
+        lib.mrz_window_scan.argtypes = [vp, vp, i64, ci, i64, i64, i64, i64, i64, i64, i64, vp, vp, vp, ci, i64p, i64p]
+        lib.mrz_set_cand_provider.argtypes = [vp, CAND_FN, vp]
         lib.mrz_set_segment_positions.argtypes = [vp, i64]
+        lib.mrz_set_candidate_capacity.argtypes = [vp, i64]
+        lib.mrz_set_xcd.argtypes = [vp, ci]
         lib.mrz_copy_to_device.argtypes = [vp, vp, vp, i64]
+        lib.mrz_copy_device.argtypes = [vp, vp, vp, i64]
     lib.mrz_stream.argtypes = [vp]
     lib.mrz_stream.restype = vp
     lib.mrz_synchronize.argtypes = [vp]
@@ -219,37 +225,76 @@ class RzipContext:
     def set_segment_positions(self, positions):
         _check(self.lib, self.lib.mrz_set_segment_positions(self.ctx, positions), self.ctx)
 
-    def window_scan(self, range_bytes, range_start, chunk_n, seg_start, seg_len, min_mask, p_done=0):
-        """mrz_window_scan: (tags, bitmap) of one segment from this rank's byte range, as bytes objects."""
-        ptr, n, where, keep = _as_ptr(range_bytes)
-        tags = ctypes.create_string_buffer(seg_len * 8)
-        bitmap = ctypes.create_string_buffer(((seg_len + 63) // 64) * 8)
-        _check(self.lib, self.lib.mrz_window_scan(self.ctx, ptr, n, where, range_start, chunk_n, seg_start, seg_len,
-                                                  min_mask, p_done, tags, bitmap), self.ctx)
-        return tags.raw, bitmap.raw
+    def set_candidate_capacity(self, entries):
+        _check(self.lib, self.lib.mrz_set_candidate_capacity(self.ctx, entries), self.ctx)
 
-    def set_tag_provider(self, provider):
-        """provider(seg_index, seg_start, seg_len, min_mask, p_done) -> (tags bytes, bitmap bytes), called by
-        rzip_chunk for every segment instead of the local tag scan; None switches back."""
+    def set_xcd(self, xcd):
+        _check(self.lib, self.lib.mrz_set_xcd(self.ctx, xcd), self.ctx)
+
+    def window_scan(self, range_bytes, range_start, chunk_n, seg_start, max_span, min_mask, p_done=0, cap=1 << 20,
+                    out=None):
+        """mrz_window_scan: one front-end pass over [seg_start, seg_start + max_span) from this rank's byte range.
+        Returns (cand, tile_off, bitmap, scan_next, n_cand).  out=None: the three buffers come back as bytes objects
+        trimmed to what the pass wrote; out=(cand, tile_off, bitmap) cuda tensors (uint8, at least cap * 16,
+        (max_span / 4096 + 1) * 4 and max_span / 8 bytes): they are filled on the device and returned as they are."""
+        ptr, n, where, keep = _as_ptr(range_bytes)
+        tiles = max_span // TILE
+        nx, nc = ctypes.c_int64(), ctypes.c_int64()
+        if out is None:
+            cand = ctypes.create_string_buffer(cap * 16)
+            toff = ctypes.create_string_buffer((tiles + 1) * 4)
+            bmp = ctypes.create_string_buffer(tiles * (TILE // 8))
+            _check(self.lib, self.lib.mrz_window_scan(self.ctx, ptr, n, where, range_start, chunk_n, seg_start, max_span,
+                                                      min_mask, p_done, cap, cand, toff, bmp, MEM_HOST, ctypes.byref(nx),
+                                                      ctypes.byref(nc)), self.ctx)
+            t = max(0, (nx.value - seg_start) // TILE)
+            return cand.raw[:nc.value * 16], toff.raw[:(t + 1) * 4], bmp.raw[:t * (TILE // 8)], nx.value, nc.value
+        cand, toff, bmp = out
+        _check(self.lib, self.lib.mrz_window_scan(self.ctx, ptr, n, where, range_start, chunk_n, seg_start, max_span,
+                                                  min_mask, p_done, cap, ctypes.c_void_p(cand.data_ptr()),
+                                                  ctypes.c_void_p(toff.data_ptr()), ctypes.c_void_p(bmp.data_ptr()),
+                                                  MEM_DEVICE, ctypes.byref(nx), ctypes.byref(nc)), self.ctx)
+        return cand, toff, bmp, nx.value, nc.value
+
+    def set_cand_provider(self, provider):
+        """provider(seg_start, max_span, min_mask, p_done, cap) -> (cand, tile_off, bitmap, scan_next, n_cand) as
+        window_scan returns them (bytes objects, or cuda tensors), called by rzip_chunk for every stretch instead of the
+        local front end; None switches back."""
         if provider is None:
-            self._tag_cb = None
-            _check(self.lib, self.lib.mrz_set_tag_provider(self.ctx, ctypes.cast(None, TAG_FN), None), self.ctx)
+            self._cand_cb = None
+            _check(self.lib, self.lib.mrz_set_cand_provider(self.ctx, ctypes.cast(None, CAND_FN), None), self.ctx)
             return
 
-        def tramp(user, seg_index, seg_start, seg_len, min_mask, p_done, d_tags, d_bitmap, stream):
+        def put(dst, src, nbytes):
+            if nbytes <= 0:
+                return 0
+            if hasattr(src, "data_ptr"):
+                if src.numel() * src.element_size() < nbytes:
+                    return 1
+                if src.is_cuda:
+                    return self.lib.mrz_copy_device(self.ctx, dst, ctypes.c_void_p(src.data_ptr()), nbytes)
+                return self.lib.mrz_copy_to_device(self.ctx, dst, ctypes.c_void_p(src.data_ptr()), nbytes)
+            if len(src) < nbytes:
+                return 1
+            return self.lib.mrz_copy_to_device(self.ctx, dst, bytes(src), nbytes)
+
+        def tramp(user, seg_start, max_span, min_mask, p_done, cap, d_cand, d_tile_off, d_bitmap, scan_next, n_cand, stream):
             try:
-                tags, bitmap = provider(seg_index, seg_start, seg_len, min_mask, p_done)
-                if len(tags) != seg_len * 8 or len(bitmap) != ((seg_len + 63) // 64) * 8:
+                cand, toff, bmp, nx, nc = provider(seg_start, max_span, min_mask, p_done, cap)
+                t = (nx - seg_start) // TILE
+                if nc < 0 or nc > cap or t < 0 or t * TILE > max_span:
                     return 1
-                if self.lib.mrz_copy_to_device(self.ctx, d_tags, tags, len(tags)):
+                if put(d_cand, cand, nc * 16) or put(d_tile_off, toff, (t + 1) * 4) or put(d_bitmap, bmp, t * (TILE // 8)):
                     return 1
-                return 1 if self.lib.mrz_copy_to_device(self.ctx, d_bitmap, bitmap, len(bitmap)) else 0
+                scan_next[0] = nx
+                n_cand[0] = nc
+                return 0
             except Exception:  # noqa: BLE001 -- must not unwind through the C frames
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._tag_cb = TAG_FN(tramp)
-        _check(self.lib, self.lib.mrz_set_tag_provider(self.ctx, self._tag_cb, None), self.ctx)
+        self._cand_cb = CAND_FN(tramp)
+        _check(self.lib, self.lib.mrz_set_cand_provider(self.ctx, self._cand_cb, None), self.ctx)
 
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.mrz_set_profiling(self.ctx, 1 if on else 0), self.ctx)

@@ -76,9 +76,13 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_index);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_state);
-    if (ctx->h_pos) hipHostFree(ctx->h_pos);
-    hipFree(ctx->d_tags);
+    if (ctx->h_ring) hipHostFree(ctx->h_ring);
+    hipFree(ctx->d_fe_hdr);
     hipFree(ctx->d_bitmap);
+    hipFree(ctx->d_tile_cnt);
+    hipFree(ctx->d_tile_off);
+    hipFree(ctx->d_grp_cnt);
+    hipFree(ctx->d_cand);
     hipFree(ctx->d_events);
     hipFree(ctx->d_block_s0);
     hipFree(ctx->d_block_s1);
@@ -125,6 +129,15 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     if (!ctx) return MRZ_E_NOMEM;
     ctx->farm_helpers = -1;
     ctx->seg_positions = MRZ_SEG_POSITIONS;
+    ctx->cand_cap = MRZ_CAND_CAP;
+    // diagnostics / test knobs, read once per ctx: never per chunk
+    {
+        const char *e = getenv("MRZ_SEQ_ENGINE");
+        if (e && !strcmp(e, "wide")) ctx->engine_pin = 1;
+        if (e && !strcmp(e, "narrow")) ctx->engine_pin = 2;
+        e = getenv("MRZ_PRINT_PROF");
+        if (e) ctx->print_prof = !strcmp(e, "narrow") ? 2 : 1;
+    }
     ctx->farm_default = mrz_sequencer_default_helpers(device);
     ctx->device = device;
     ctx->level = level;
@@ -148,9 +161,8 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_index, &cap, 256); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tab, &cap, ctx->nslots); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_state, &cap, 1); }
-    if (!rc && hipHostMalloc((void **)&ctx->h_pos, 256) != hipSuccess) rc = MRZ_E_NOMEM;
-    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_tags, &cap, MRZ_SEG_POSITIONS); }
-    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_bitmap, &cap, MRZ_SEG_POSITIONS / 16 + 64); }
+    if (!rc && hipHostMalloc((void **)&ctx->h_ring, MRZ_SEG_AHEAD * sizeof(mrz_seq_state)) != hipSuccess) rc = MRZ_E_NOMEM;
+    if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_fe_hdr, &cap, 1); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_totals, &cap, 1); }
     if (!rc) { cap = 0; rc = mrz_grow(ctx, &ctx->d_crc_out, &cap, 4); }
     if (!rc) {
@@ -192,6 +204,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
     if (!rc && max_chunk > 0) {
         rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, max_chunk / MRZ_MIN_MATCH + 2);
         if (!rc) rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(max_chunk));
+        if (!rc) rc = mrz_fe_reserve(ctx, max_chunk / MRZ_TILE + 2, max_chunk);
     }
     if (rc) {
         mrz_close(ctx);
@@ -236,56 +249,132 @@ extern "C" int mrz_fetch_events(mrz_ctx *ctx, int64_t first, int64_t count, mrz_
     return MRZ_OK;
 }
 
-extern "C" int mrz_set_tag_provider(mrz_ctx *ctx, mrz_tag_provider_fn fn, void *user) {
+extern "C" int mrz_set_cand_provider(mrz_ctx *ctx, mrz_cand_provider_fn fn, void *user) {
     if (!ctx) return MRZ_E_ARG;
-    ctx->tag_fn = fn;
-    ctx->tag_user = user;
+    ctx->cand_fn = fn;
+    ctx->cand_user = user;
     return MRZ_OK;
 }
 
 extern "C" int mrz_copy_to_device(mrz_ctx *ctx, void *dst_device, const void *src_host, int64_t n) {
     if (!ctx || n < 0 || (n > 0 && (!dst_device || !src_host))) return MRZ_E_ARG;
     if (!n) return MRZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(dst_device, src_host, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the source may be reused on return
     return MRZ_OK;
 }
 
+extern "C" int mrz_copy_device(mrz_ctx *ctx, void *dst_device, const void *src_device, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && (!dst_device || !src_device))) return MRZ_E_ARG;
+    if (!n) return MRZ_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst_device, src_device, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MRZ_OK;
+}
+
 extern "C" int mrz_set_segment_positions(mrz_ctx *ctx, int64_t positions) {
-    if (!ctx || positions < 4096 || positions > MRZ_SEG_POSITIONS || positions % 4096) return MRZ_E_ARG;
+    if (!ctx || positions < MRZ_TILE || positions > MRZ_SEG_POSITIONS || positions % MRZ_TILE) return MRZ_E_ARG;
     ctx->seg_positions = positions;
     return MRZ_OK;
 }
 
+extern "C" int mrz_set_candidate_capacity(mrz_ctx *ctx, int64_t entries) {
+    if (!ctx || entries < MRZ_TILE || entries > (1ll << 30)) return MRZ_E_ARG;
+    ctx->cand_cap = entries;
+    return MRZ_OK;
+}
+
+extern "C" int mrz_set_xcd(mrz_ctx *ctx, int xcd) {
+    if (!ctx || xcd < 0 || xcd > 7) return MRZ_E_ARG;
+    ctx->xcd = xcd;
+    return MRZ_OK;
+}
+
+// the front end's buffers: passes of up to `tiles` tiles, lists of up to `entries` candidates
+int mrz_fe_reserve(mrz_ctx *ctx, int64_t tiles, int64_t entries) {
+    const int64_t max_tiles = ctx->seg_positions / MRZ_TILE;
+    if (tiles > max_tiles) tiles = max_tiles;
+    if (tiles < 1) tiles = 1;
+    if (entries > ctx->cand_cap) entries = ctx->cand_cap;
+    if (entries < MRZ_TILE) entries = MRZ_TILE;
+    if (tiles > ctx->fe_tiles_cap) {
+        int64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (ctx->d_bitmap) hipFree(ctx->d_bitmap), ctx->d_bitmap = nullptr;
+        if (ctx->d_tile_cnt) hipFree(ctx->d_tile_cnt), ctx->d_tile_cnt = nullptr;
+        if (ctx->d_tile_off) hipFree(ctx->d_tile_off), ctx->d_tile_off = nullptr;
+        if (ctx->d_grp_cnt) hipFree(ctx->d_grp_cnt), ctx->d_grp_cnt = nullptr;
+        ctx->fe_tiles_cap = 0;
+        int rc = mrz_grow(ctx, &ctx->d_bitmap, &c0, tiles * (MRZ_TILE / 16) + 64);
+        if (!rc) rc = mrz_grow(ctx, &ctx->d_tile_cnt, &c1, tiles + 1);
+        if (!rc) rc = mrz_grow(ctx, &ctx->d_tile_off, &c2, tiles + 2);
+        if (!rc) rc = mrz_grow(ctx, &ctx->d_grp_cnt, &c3, tiles / MRZ_FE_GROUP + 2);
+        if (rc) return rc;
+        ctx->fe_tiles_cap = tiles;
+    }
+    return mrz_grow(ctx, &ctx->d_cand, &ctx->cand_alloc, entries);
+}
+
 extern "C" int mrz_window_scan(mrz_ctx *ctx, const void *range_bytes, int64_t range_len, int where, int64_t range_start,
-                               int64_t chunk_n, int64_t seg_start, int64_t seg_len, int64_t min_mask, int64_t p_done,
-                               int64_t *tags_out, uint64_t *bitmap_out) {
-    if (!ctx || !range_bytes || !tags_out || !bitmap_out || range_len <= 0 || range_start < 0 || chunk_n <= 0)
+                               int64_t chunk_n, int64_t seg_start, int64_t max_span, int64_t min_mask, int64_t p_done,
+                               int64_t cap, mrz_candidate *cand_out, int32_t *tile_off_out, void *bitmap_out, int out_where,
+                               int64_t *scan_next, int64_t *n_cand) {
+    if (!ctx || !range_bytes || !cand_out || !tile_off_out || !bitmap_out || !scan_next || !n_cand) return MRZ_E_ARG;
+    if (range_len <= 0 || range_start < 0 || chunk_n <= 0 || cap < MRZ_TILE) return MRZ_E_ARG;
+    if (max_span <= 0 || max_span > ctx->seg_positions || max_span % MRZ_TILE || seg_start % MRZ_TILE || seg_start < range_start)
         return MRZ_E_ARG;
-    if (seg_len <= 0 || seg_len > MRZ_SEG_POSITIONS || seg_start < range_start) return MRZ_E_ARG;
-    // the last position's 31-byte window must lie in the rank's bytes (or the chunk ends first)
-    const int64_t last_pos = seg_start + seg_len - 1;
-    // (the kernel stages whole 16-byte pieces: 48 bytes of halo keep every load inside the rank's bytes)
+    if (out_where != MRZ_MEM_HOST && out_where != MRZ_MEM_DEVICE) return MRZ_E_ARG;
+    // the last position's 31-byte window must lie in the rank's bytes (or the chunk ends first); the kernels stage whole
+    // 16-byte pieces: 48 bytes of halo keep every load inside the rank's bytes
+    const int64_t end = chunk_n - MRZ_MIN_MATCH;
+    int64_t last_pos = seg_start + max_span - 1;
+    if (last_pos > end) last_pos = end;
     const int64_t need_end = last_pos + 48 < chunk_n ? last_pos + 48 : chunk_n;
-    if (need_end > range_start + range_len) return MRZ_E_ARG;
-    if (seg_len % 4096 && seg_start + seg_len + MRZ_MIN_MATCH <= chunk_n) return MRZ_E_ARG;  // whole tiles, or the chunk's tail
+    if (last_pos >= seg_start && need_end > range_start + range_len) return MRZ_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint8_t *d_range = nullptr;
     int rc = mrz_stage_input(ctx, range_bytes, range_len, where, &d_range);
     if (rc) return rc;
+    const int64_t tiles = max_span / MRZ_TILE;
+    const int64_t save_cap = ctx->cand_cap;
+    if (cap > ctx->cand_cap) ctx->cand_cap = cap;
+    rc = mrz_fe_reserve(ctx, tiles, cap);
+    ctx->cand_cap = save_cap;
+    if (rc) return rc;
     mrz_seq_state hs;
     memset(&hs, 0, sizeof(hs));
-    hs.p = p_done;
+    hs.n = chunk_n;
+    hs.end = end;
+    // (a matcher position inside or beyond the stretch's first tile would move the pass's first tile: the outputs are
+    // laid out from seg_start, so such a position is not used as a filter -- the list is a superset then)
+    hs.p = p_done + 1 < seg_start + MRZ_TILE ? p_done : seg_start - 1;
     hs.min_mask = min_mask;
+    hs.scan_next = seg_start;
     hipStream_t s = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, s));
-    // the kernel indexes the chunk by absolute position: give it the pointer position 0 would have.  It stays
+    // the kernels index the chunk by absolute position: give them the pointer position 0 would have.  They stay
     // inside [range_start, need_end + 16) of it; the staging buffer is padded by 64 bytes.
-    HIPCHK(ctx, mrz_launch_tagscan(s, d_range - range_start, chunk_n, seg_start, seg_len, ctx->d_index, ctx->d_state,
-                                   ctx->d_tags, ctx->d_bitmap));
-    HIPCHK(ctx, hipMemcpyAsync(tags_out, ctx->d_tags, (size_t)seg_len * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipMemcpyAsync(bitmap_out, ctx->d_bitmap, (size_t)((seg_len + 63) / 64) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, mrz_launch_frontend(s, d_range - range_start, chunk_n, ctx->d_index, ctx->d_state, (int)tiles, cap,
+                                    ctx->d_fe_hdr, ctx->d_bitmap, ctx->d_tile_cnt, ctx->d_tile_off, ctx->d_grp_cnt, ctx->d_cand));
+    HIPCHK(ctx, hipMemcpyAsync(&hs, ctx->d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
+    int64_t T = (hs.scan_next - seg_start) / MRZ_TILE;  // tiles the pass covered (none: the matcher is past the stretch)
+    if (hs.seg_start != seg_start || T < 0 || T > tiles) {
+        // (p_done lies beyond the stretch: the pass began further on; report the stretch as empty)
+        T = 0;
+        hs.n_cand = 0;
+        hs.scan_next = hs.scan_next > seg_start ? hs.scan_next : seg_start;
+    }
+    const hipMemcpyKind k = out_where == MRZ_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (hs.n_cand > 0) HIPCHK(ctx, hipMemcpyAsync(cand_out, ctx->d_cand, (size_t)hs.n_cand * sizeof(mrz_cand), k, s));
+    if (T > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(tile_off_out, ctx->d_tile_off, (size_t)(T + 1) * sizeof(int), k, s));
+        HIPCHK(ctx, hipMemcpyAsync(bitmap_out, ctx->d_bitmap, (size_t)T * (MRZ_TILE / 8), k, s));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    *scan_next = hs.scan_next;
+    *n_cand = hs.n_cand;
     return MRZ_OK;
 }
 
@@ -294,10 +383,6 @@ extern "C" int mrz_set_farm_helpers(mrz_ctx *ctx, int n) {
     ctx->farm_helpers = n < 0 ? -1 : n;
     return MRZ_OK;
 }
-
-// Several ctxs of one process only overlap on the device if the HIP runtime may open enough hardware queues
-// (every ctx has two streams); the runtime reads this once, when it initialises.  Harmless if already set.
-__attribute__((constructor)) static void mrz_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int mrz_get_timings(const mrz_ctx *ctx, mrz_timings *out) {
     if (!ctx || !out) return MRZ_E_ARG;
@@ -343,12 +428,19 @@ extern "C" int mrz_crc32(mrz_ctx *ctx, const void *buf, int64_t n, int where, ui
     return MRZ_OK;
 }
 
-#define MRZ_SEG_AHEAD 4  // segment launches the host keeps queued ahead of the device
-
 struct mrz_evpair {
     hipEvent_t a, b;
-    int kind;  // 0 tagscan, 1 sequencer, 2 encode, 3 crc
+    int kind;  // 0 front end, 1 sequencer, 2 encode, 3 crc
 };
+
+// positions a front-end pass should look at under a mask of k bits so that its list comes out about 3/4 full
+static int64_t mrz_span_for_mask(const mrz_ctx *ctx, int64_t mask) {
+    const int k = __builtin_popcountll((unsigned long long)mask);
+    int64_t span = (ctx->cand_cap - ctx->cand_cap / 4) << (k < 24 ? k : 24);
+    if (span > ctx->seg_positions) span = ctx->seg_positions;
+    span = span / MRZ_TILE * MRZ_TILE;
+    return span < MRZ_TILE ? MRZ_TILE : span;
+}
 
 extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int where, int chunk_bytes,
                               int64_t *victim_round, mrz_chunk_result *res) {
@@ -368,30 +460,36 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     if (rc) return rc;
     rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(n));
     if (rc) return rc;
+    const int64_t end = n - MRZ_MIN_MATCH;  // last position that is looked up (src/rzip.c:544)
+    if (end > 0) {
+        rc = mrz_fe_reserve(ctx, end / MRZ_TILE + 2, end + 1);
+        if (rc) return rc;
+    }
 
     // profiling events (optional)
     mrz_evpair *evs = nullptr;
     int nev = 0, evcap = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    const int64_t end = n - MRZ_MIN_MATCH;
-    const int64_t SEGP = ctx->seg_positions;
-    const int64_t nseg = end > 0 ? (end + 1 + SEGP - 1) / SEGP : 0;
     if (ctx->profiling) {
-        evcap = (int)(2 * nseg + 4);
-        evs = (mrz_evpair *)calloc((size_t)evcap, sizeof(mrz_evpair));
-        if (!evs) return MRZ_E_NOMEM;
         hipEventCreate(&ev_begin);
         hipEventCreate(&ev_end);
         hipEventRecord(ev_begin, s);
     }
-#define PROF_BEGIN(k)                                  \
-    do {                                               \
-        if (ctx->profiling && nev < evcap) {           \
-            evs[nev].kind = (k);                       \
-            hipEventCreate(&evs[nev].a);               \
-            hipEventCreate(&evs[nev].b);               \
-            hipEventRecord(evs[nev].a, s);             \
-        }                                              \
+#define PROF_BEGIN(k)                                                                       \
+    do {                                                                                    \
+        if (ctx->profiling) {                                                               \
+            if (nev == evcap) {                                                             \
+                const int ncap__ = evcap ? evcap * 2 : 64;                                  \
+                mrz_evpair *ne__ = (mrz_evpair *)realloc(evs, (size_t)ncap__ * sizeof(mrz_evpair)); \
+                if (ne__) evs = ne__, evcap = ncap__;                                       \
+            }                                                                               \
+            if (nev < evcap) {                                                              \
+                evs[nev].kind = (k);                                                        \
+                hipEventCreate(&evs[nev].a);                                                \
+                hipEventCreate(&evs[nev].b);                                                \
+                hipEventRecord(evs[nev].a, s);                                              \
+            }                                                                               \
+        }                                                                                   \
     } while (0)
 #define PROF_END()                                     \
     do {                                               \
@@ -432,91 +530,132 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     STEP(mrz_launch_crc32(s, d_buf, n, ctx->d_crc_tables, ctx->d_crc_parts, ctx->d_crc_out));
     PROF_END();
 
-    // The host stays MRZ_SEG_AHEAD segments ahead of the device and looks at the matcher's position of the
-    // segment that has just finished: a segment that an emitted match has already covered completely (a stream
-    // that repeats itself: one match of gigabytes) needs no tag scan and no sequencer launch at all.
-    int64_t *h_pos = ctx->h_pos;  // pinned; written by the copies below: p, hint_positions, hint_events, hint_matched
-    for (int k = 0; k < 8; k++) h_pos[k] = 0;  // [4] last_match, [5] n_events, [6] min_mask of the latest finished launch
-    h_pos[6] = (1ll << ctx->initial_freq) - 1;
+    // ---- the segments: a front-end pass (candidate list of the next stretch) and a sequencer launch over it, again
+    // and again until the matcher reports the end of the chunk.  WHERE a pass begins and ends is device state (it goes
+    // on behind the last one, skips what an emitted match has covered, and stops where its list is full); the host
+    // only bounds the span of a pass -- from the mask the matcher has reached: the tighter the mask, the more
+    // positions a list of the same size covers -- and keeps MRZ_SEG_AHEAD segments queued.  Every launch leaves a
+    // snapshot of the matcher state in a ring of pinned host slots (ONE copy per launch: position, masks, progress and
+    // the `finished` flag belong together); the host reads a slot once the launch's event has completed.
     ctx->events_final = 0;
-    int engine_pin = 0, n_narrow = 0;
-    {
-        const char *e = getenv("MRZ_SEQ_ENGINE");
-        if (e && !strcmp(e, "wide")) engine_pin = 1;
-        if (e && !strcmp(e, "narrow")) engine_pin = 2;
-    }
+    const size_t snap_bytes = offsetof(mrz_seq_state, prof);
     hipEvent_t seg_ev[MRZ_SEG_AHEAD];
     int n_seg_ev = 0;
     for (int k = 0; k < MRZ_SEG_AHEAD && herr == hipSuccess; k++) {
         STEP(hipEventCreateWithFlags(&seg_ev[k], hipEventDisableTiming));
         if (herr == hipSuccess) n_seg_ev++;
     }
-    int64_t launched = 0;
-    for (int64_t sg = 0; sg < nseg && herr == hipSuccess; sg++) {
-        const int64_t seg_start = sg * SEGP;
-        int64_t seg_len = end + 1 - seg_start;
-        if (seg_len > SEGP) seg_len = SEGP;
-        if (launched >= MRZ_SEG_AHEAD) {
-            STEP(hipEventSynchronize(seg_ev[launched % MRZ_SEG_AHEAD]));  // the launch MRZ_SEG_AHEAD back is done
-            if (herr == hipSuccess && ctx->progress_fn) {
-                // what that launch (or a later one that has finished meanwhile) has left is final
-                const int64_t ne = *(volatile int64_t *)(h_pos + 5), lm = *(volatile int64_t *)(h_pos + 4);
-                ctx->events_final = ne;
-                if (ctx->progress_fn(ctx->progress_user, ne, lm, 0)) {
+    int64_t launched = 0, retired = 0, n_narrow = 0;
+    int64_t span_of[MRZ_SEG_AHEAD];      // positions the pass of an in-flight launch may cover
+    int64_t known_next = 0;              // where the pass after the last retired launch begins, as far as the host knows
+    int64_t known_mask = hs.min_mask, known_p = 0;
+    int64_t hint_pos = 0, hint_matched = 0;
+    bool finished = end <= 0;
+    // a launch whose event has completed: its snapshot is final
+    auto retire = [&]() {
+        const mrz_seq_state *sn = &ctx->h_ring[retired % MRZ_SEG_AHEAD];
+        retired++;
+        known_p = sn->p;
+        known_mask = sn->min_mask;
+        if (!ctx->cand_fn) known_next = sn->scan_next;
+        hint_pos = sn->hint_positions;
+        hint_matched = sn->hint_matched;
+        if (ctx->progress_fn) {
+            ctx->events_final = sn->n_events;
+            if (ctx->progress_fn(ctx->progress_user, sn->n_events, sn->last_match, 0)) rc = MRZ_E_STATE;
+        }
+        if (sn->finished || sn->error) finished = true;
+    };
+    while (!finished && herr == hipSuccess && !rc) {
+        // whatever has completed meanwhile (the engine choice and the span below want the matcher's latest news)
+        while (retired < launched && !finished && !rc && hipEventQuery(seg_ev[retired % MRZ_SEG_AHEAD]) == hipSuccess) retire();
+        if (finished || rc) break;
+        // where the queued passes will have got to if none of them is cut short
+        int64_t est_next = known_next;
+        for (int64_t k = retired; k < launched; k++) est_next += span_of[k % MRZ_SEG_AHEAD];
+        const bool queue_full = launched - retired >= MRZ_SEG_AHEAD;
+        const bool all_queued = est_next > end;  // (only a list that fills up -- or the provider -- can prove this wrong)
+        if (queue_full || (all_queued && launched > retired)) {
+            STEP(hipEventSynchronize(seg_ev[retired % MRZ_SEG_AHEAD]));  // wait for the oldest launch
+            if (herr != hipSuccess) break;
+            retire();
+            continue;
+        }
+        if (all_queued) {
+            // nothing in flight and, by the host's book-keeping, nothing left -- yet the matcher has not reported the end:
+            // cannot happen (a pass always covers its span unless its list fills, and then known_next says so)
+            rc = MRZ_E_OVERFLOW;
+            break;
+        }
+        // ---- one more segment
+        int64_t span = mrz_span_for_mask(ctx, known_mask);
+        int64_t max_tiles = span / MRZ_TILE;
+        if (max_tiles > ctx->fe_tiles_cap) max_tiles = ctx->fe_tiles_cap;
+        span = max_tiles * MRZ_TILE;
+        PROF_BEGIN(0);
+        if (ctx->cand_fn) {
+            // window sharding: the stretch's owner scans it (with the mask this rank has last heard of); the host drives
+            // the geometry here, and hands it to the sequencer through the matcher state
+            int64_t seg_start = known_next;
+            const int64_t pt = (known_p + 1) / MRZ_TILE * MRZ_TILE;
+            if (pt > seg_start) seg_start = pt;
+            if (seg_start > end) {  // (the matcher is about to report the end)
+                known_next = seg_start;
+                span_of[launched % MRZ_SEG_AHEAD] = 0;
+            } else {
+                if (seg_start + span > end + 1) span = (end + 1 - seg_start + MRZ_TILE - 1) / MRZ_TILE * MRZ_TILE;
+                int64_t geo[5] = { seg_start, 0, 0, 0, known_mask };  // seg_start, seg_end, n_cand, scan_next, list_mask
+                int64_t nx = seg_start, nc = 0;
+                if (herr == hipSuccess && ctx->cand_fn(ctx->cand_user, seg_start, span, known_mask, known_p, ctx->cand_cap,
+                                                       (mrz_candidate *)ctx->d_cand, ctx->d_tile_off, ctx->d_bitmap, &nx, &nc,
+                                                       (void *)s)) {
                     hipStreamSynchronize(s);
                     rc = MRZ_E_STATE;
                     break;
                 }
+                if (nx <= seg_start || nx > seg_start + span || nx % MRZ_TILE || nc < 0 || nc > ctx->cand_cap) {
+                    hipStreamSynchronize(s);
+                    rc = MRZ_E_STATE;
+                    break;
+                }
+                geo[1] = nx < end + 1 ? nx : end + 1;
+                geo[2] = nc;
+                geo[3] = nx;
+                STEP(hipMemcpyAsync(&ctx->d_state->seg_start, geo, sizeof(geo), hipMemcpyHostToDevice, s));
+                STEP(hipStreamSynchronize(s));  // (geo lives on this stack frame)
+                known_next = nx;
+                span_of[launched % MRZ_SEG_AHEAD] = 0;
             }
-            // positions are only ever visited in order: the last candidate of this segment is seg_start + seg_len - 1
-            if (herr == hipSuccess && *(volatile int64_t *)h_pos >= seg_start + seg_len - 1) continue;
+        } else {
+            STEP(mrz_launch_frontend(s, d_buf, n, ctx->d_index, ctx->d_state, (int)max_tiles, ctx->cand_cap, ctx->d_fe_hdr,
+                                     ctx->d_bitmap, ctx->d_tile_cnt, ctx->d_tile_off, ctx->d_grp_cnt, ctx->d_cand));
+            span_of[launched % MRZ_SEG_AHEAD] = span;
         }
-        PROF_BEGIN(0);
-        if (ctx->tag_fn) {
-            // window sharding: the segment's owner has scanned it (with the mask this rank had last reported)
-            if (herr == hipSuccess &&
-                ctx->tag_fn(ctx->tag_user, sg, seg_start, seg_len, *(volatile int64_t *)(h_pos + 6),
-                            *(volatile int64_t *)h_pos, ctx->d_tags, (uint64_t *)ctx->d_bitmap, (void *)s)) {
-                hipStreamSynchronize(s);
-                rc = MRZ_E_STATE;
-                break;
-            }
-        } else
-            STEP(mrz_launch_tagscan(s, d_buf, n, seg_start, seg_len, ctx->d_index, ctx->d_state, ctx->d_tags,
-                                    ctx->d_bitmap));
         PROF_END();
         // Which engine: the wide one (512 candidates per batch) unless the segments before were one long match after
         // another (>= 80 % of the positions a launch advanced over lay inside the matches it emitted): then the
-        // narrow engine's shorter chain per match wins.  The hint lags behind like h_pos; the first two launches are
-        // waited for so that it arrives early.  MRZ_SEQ_ENGINE=wide|narrow pins the choice (tests, measurements).
-        bool narrow = false;
-        {
-            const int64_t hp = *(volatile int64_t *)(h_pos + 1), hm = *(volatile int64_t *)(h_pos + 3);
-            narrow = hp > 0 && hm * 10 >= hp * 8;
-            if (engine_pin) narrow = engine_pin == 2;
-        }
+        // narrow engine's shorter chain per match wins.  The hint lags behind like everything the host knows; the first
+        // two launches are waited for so that it arrives early.  MRZ_SEQ_ENGINE=wide|narrow pins the choice (tests,
+        // measurements).
+        bool narrow = hint_pos > 0 && hint_matched * 10 >= hint_pos * 8;
+        if (ctx->engine_pin) narrow = ctx->engine_pin == 2;
         const int helpers = ctx->farm_helpers >= 0 && ctx->farm_helpers < ctx->farm_default ? ctx->farm_helpers : ctx->farm_default;
         PROF_BEGIN(1);
         if (narrow)
-            STEP(mrz_launch_sequencer_narrow(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                             ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers));
+            STEP(mrz_launch_sequencer_narrow(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
+                                             ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->xcd));
         else
-            STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_tags, (const mrz_u64 *)ctx->d_bitmap, ctx->d_events,
-                                      ctx->d_state, seg_start, seg_len, ctx->d_gmailbox, helpers, ctx->d_seq_shared, ctx->d_wlog,
-                                      ctx->nslots, ctx->seq_wgs));
+            STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
+                                      ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->d_seq_shared, ctx->d_wlog,
+                                      ctx->nslots, ctx->seq_wgs, ctx->xcd));
         PROF_END();
         if (narrow) n_narrow++;
-        STEP(hipMemcpyAsync(h_pos, &ctx->d_state->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        STEP(hipMemcpyAsync(h_pos + 1, &ctx->d_state->hint_positions, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        if (ctx->tag_fn) STEP(hipMemcpyAsync(h_pos + 6, &ctx->d_state->min_mask, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        if (ctx->progress_fn) {
-            STEP(hipMemcpyAsync(h_pos + 4, &ctx->d_state->last_match, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            STEP(hipMemcpyAsync(h_pos + 5, &ctx->d_state->n_events, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        }
-        if (launched < 2 && !engine_pin) STEP(hipStreamSynchronize(s));
+        STEP(hipMemcpyAsync(&ctx->h_ring[launched % MRZ_SEG_AHEAD], ctx->d_state, snap_bytes, hipMemcpyDeviceToHost, s));
         STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));
         launched++;
+        if (launched <= 2 && !ctx->engine_pin && !ctx->cand_fn) STEP(hipStreamSynchronize(s));
     }
+    hipStreamSynchronize(s);  // (also after a refusal of the progress hook: the queued launches run out)
     for (int k = 0; k < n_seg_ev; k++) hipEventDestroy(seg_ev[k]);
     STEP(hipMemcpyAsync(&hs, ctx->d_state, sizeof(hs), hipMemcpyDeviceToHost, s));
     STEP(hipMemcpyAsync(&crc, ctx->d_crc_out, 4, hipMemcpyDeviceToHost, s));
@@ -525,9 +664,10 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         if (!rc && (hs.error || !hs.finished)) {
             fprintf(stderr,
                     "libmrzgpu: sequencer stopped abnormally: error=%d finished=%d p=%lld end=%lld events=%lld/%lld "
-                    "count=%lld min_mask=%lld\n",
+                    "count=%lld min_mask=%lld scan_next=%lld launches=%lld\n",
                     hs.error, hs.finished, (long long)hs.p, (long long)hs.end, (long long)hs.n_events,
-                    (long long)hs.event_cap, (long long)hs.count, (long long)hs.min_mask);
+                    (long long)hs.event_cap, (long long)hs.count, (long long)hs.min_mask, (long long)hs.scan_next,
+                    (long long)launched);
             rc = MRZ_E_OVERFLOW;
         }
         E = hs.n_events;
@@ -563,7 +703,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         STEP(hipStreamSynchronize(s));
     }
 
-    ctx->timings.n_segments = (int32_t)launched;  // segments covered by an emitted match are not launched
+    ctx->timings.n_segments = (int32_t)launched;
     ctx->timings.n_narrow = (int32_t)n_narrow;
     if (ctx->profiling) {
         hipStreamSynchronize(s);
@@ -612,29 +752,21 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     res->min_mask = hs.min_mask;
     res->hash_count = hs.count;
     res->n_events = E;
-    if (getenv("MRZ_PRINT_PROF")) {
-        static const char *names[96] = { "batches", "formed", "committed", "segments", "emits", "backjump", "rewalk",
-                                         "longres", "seq_cands", "cut_cplx", "cut_overflow", "skipout", "conf0", "pairs",
-                                         "t_form", "t_walk", "t_conf", "t_pairs", "t_loop", "t_rewalk", "t_long", "t_seq",
-                                         "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
-                                         "f_fold", "s_tab", "s_pair", "s_ins", "ovl", "ovl_ok", "x_walk", "x_casc", "x_pool",
-                                         "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw", "t_ovl",
-                                         "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit", "reprep", "w_stale", "w_drop", "reset",
-                                         "t_turn", "t_prep", "t_precommit", "e_mask", "e_cull", "e_xw", "e_inwin", "e_window", "e_bulk",
-                                         "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk", "t_turnwork", "t_snap", "rebulk" };
-        // (the narrow engine keeps its own list: MRZ_PRINT_PROF=narrow prints with its names; meaningful when
-        // MRZ_SEQ_ENGINE=narrow pinned the engine)
-        static const char *narrow_names[96] = { "batches", "batch_lanes", "seq", "cut_long", "cut_walk", "cut_conflict", "cut_cull",
-                                                "batch_emits", "cut_cascade", "pairs", "batch_formed", "t_form", "t_walk", "t_walk2",
-                                                "t_pairs", "t_scans", "t_conflict", "t_commit", "t_seq", "t_window", "t_long", "t_fold",
-                                                "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
-                                                "f_fold", "f_helper", "h_fields", "h_fwd", "h_bwd", "h_drain", "h_rounds", "s_tab",
-                                                "s_pair", "s_ins" };
-        const bool nn = !strcmp(getenv("MRZ_PRINT_PROF"), "narrow");
-        for (int k = 0; k < 96; k++) {
-            const char *nm = nn ? narrow_names[k] : names[k];
-            if (nm) fprintf(stderr, "seqstat %-12s %lld\n", nm, (long long)hs.prof[k]);
-        }
+    if (ctx->print_prof) {
+        // (one list for both engines: the enum of mrz_seq_common.h)
+        static const char *names[128] = { "batches", "formed", "committed", "segments", "emits", "backjump", "rewalk",
+                                          "longres", "seq_cands", "cut_cplx", "cut_overflow", "skipout", "conf0", "pairs",
+                                          "t_form", "t_walk", "t_conf", "t_pairs", "t_loop", "t_rewalk", "t_long", "t_seq",
+                                          "farmed", "l_post", "l_stripe", "l_bwd", "l_wait", "l_rounds", "f_post", "f_wait",
+                                          "f_fold", "s_tab", "s_pair", "s_ins", "ovl", "ovl_ok", "x_walk", "x_casc", "x_pool",
+                                          "x_win", "x_same", "c_win", "c_evict", "c_deep", "c_many", "c_fail", "c_tie", "c_nw", "t_ovl",
+                                          "h_pre", "h_cand", "h_post", "t_scan", "t_fold", "t_commit", "reprep", "w_stale", "w_drop", "reset",
+                                          "t_turn", "t_prep", "t_precommit", "e_mask", "e_cull", "e_xw", "e_inwin", "e_window", "e_bulk",
+                                          "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk", "t_turnwork", "t_snap", "rebulk",
+                                          "batch_lanes", "cut_long", "cut_walk", "cut_conflict", "cut_cull", "batch_emits",
+                                          "cut_cascade", "batch_formed", "t_walk2", "t_scans", "t_conflict", "t_window" };
+        for (int k = 0; k < 128; k++)
+            if (names[k] && hs.prof[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }
     return MRZ_OK;
 }

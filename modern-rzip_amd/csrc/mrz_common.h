@@ -47,9 +47,33 @@ struct mrz_seq_state {
     int64_t hint_positions;  // regime hint of the latest launch: positions it advanced over ...
     int64_t hint_events;     // ... matches it emitted ...
     int64_t hint_matched;    // ... and the bytes those matches cover (most positions matched = one long match after another)
-    int64_t pad[5];
-    int64_t prof[96];     // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
+    // the segment the front end (mrz_tagscan.hip) has laid out for the next sequencer launch: a compacted, position-ordered
+    // list of the candidates of [seg_start, seg_end) -- the positions whose tag passed minimum_tag_mask (src/rzip.c:573)
+    // at the time of the scan (list_mask; masks only tighten, so the list is a superset the sequencer re-checks)
+    int64_t seg_start;       // first position covered (a multiple of 4096)
+    int64_t seg_end;         // one past the last position covered
+    int64_t n_cand;          // entries of the list
+    int64_t scan_next;       // where the next front-end pass begins
+    int64_t list_mask;       // minimum_tag_mask the list was made under
+    int64_t prof[128];    // cycle accumulators of a -DMRZ_SEQ_PROFILE build (diagnostics only)
 };
+
+// One candidate of the front end's list: a position whose tag passes the mask.  Same 16 bytes as struct hash_entry
+// (mrz_slot): off = position in the chunk, t = tag.
+typedef mrz_slot mrz_cand;
+
+// header the front-end kernels of one pass share (device memory)
+struct mrz_fe_hdr {
+    int64_t base;     // first position of the pass (tile-aligned)
+    int64_t mask;     // minimum_tag_mask it filters with
+    int64_t p_done;   // positions up to here need no candidates (the matcher has passed them)
+    int32_t ntiles;   // 4096-position tiles it looks at
+    int32_t T;        // ... and how many of them fit the list (set by the scan kernel)
+};
+
+#define MRZ_TILE 4096          // positions per front-end tile (one 256-thread workgroup)
+#define MRZ_TILE_SHIFT 12
+#define MRZ_FE_GROUP 256       // tiles per group of the offset scan
 
 // result of the record-sizing pass
 struct mrz_enc_totals {

@@ -7,8 +7,12 @@
 #include "../../include/mrzgpu.h"
 #include "mrz_kernels.h"
 
-// positions per segment: tags 8 B/position -> 128 MiB scratch, bitmap 2 MiB
-#define MRZ_SEG_POSITIONS (16ll << 20)
+// One segment = one front-end pass + one sequencer launch.  A pass looks at up to MRZ_SEG_POSITIONS positions
+// (bitmap 1 bit, tile counters 8 B per 4096 of them) and ends early where its candidate list is full
+// (MRZ_CAND_CAP entries of 16 B): under a k-bit mask a segment covers about (3/4 cap) << k positions.
+#define MRZ_SEG_POSITIONS (1ll << 30)
+#define MRZ_CAND_CAP (8ll << 20)
+#define MRZ_SEG_AHEAD 4  // segment launches the host keeps queued ahead of the device
 
 struct mrz_ctx {
     int device;
@@ -25,9 +29,18 @@ struct mrz_ctx {
     int64_t *d_index;
     mrz_slot *d_tab;
     mrz_seq_state *d_state;
-    int64_t *h_pos;  // pinned host word: the matcher's position after the latest finished segment
-    int64_t *d_tags;
-    uint16_t *d_bitmap;
+    mrz_seq_state *h_ring;  // pinned: the matcher state as every one of the last MRZ_SEG_AHEAD launches left it
+    // the front end's buffers (mrz_tagscan.hip): grown to what a chunk needs
+    mrz_fe_hdr *d_fe_hdr;
+    uint16_t *d_bitmap;  // 1 bit per position of a pass
+    int *d_tile_cnt, *d_tile_off, *d_grp_cnt;
+    int64_t fe_tiles_cap;  // tiles the four arrays above hold
+    mrz_cand *d_cand;
+    int64_t cand_alloc;    // entries d_cand holds
+    int64_t cand_cap;      // entries a pass may fill (MRZ_CAND_CAP unless a test shrinks it)
+    int engine_pin;        // MRZ_SEQ_ENGINE at mrz_open: 0 per-segment choice, 1 wide, 2 narrow
+    int print_prof;        // MRZ_PRINT_PROF at mrz_open
+    int xcd;               // block index mod 8 of this ctx's sequencer workgroups (concurrent ctxs: one XCD each)
     mrz_event *d_events;
     int64_t event_cap;
     int64_t *d_block_s0, *d_block_s1;
@@ -71,9 +84,9 @@ struct mrz_ctx {
     mrz_progress_fn progress_fn;
     void *progress_user;
     int64_t events_final;     // matches of the chunk in flight that are final (mrz_fetch_events bound)
-    int64_t seg_positions;    // positions per segment launch (MRZ_SEG_POSITIONS unless a test shrinks it)
-    mrz_tag_provider_fn tag_fn;  // window sharding: another rank scans the tags of a segment
-    void *tag_user;
+    int64_t seg_positions;    // positions per front-end pass at most (MRZ_SEG_POSITIONS unless a test shrinks it)
+    mrz_cand_provider_fn cand_fn;  // window sharding: the rank that owns a stretch of the window scans it
+    void *cand_user;
 };
 
 #define HIPCHK(ctx, expr)                     \
@@ -105,6 +118,9 @@ static inline int mrz_grow(mrz_ctx *ctx, T **ptr, int64_t *cap, int64_t want) {
     return MRZ_OK;
 }
 
+
+// (re)allocates the front end's buffers for passes of up to `tiles` tiles and lists of up to `entries` candidates
+int mrz_fe_reserve(mrz_ctx *ctx, int64_t tiles, int64_t entries);
 
 // resolves a caller buffer to a device pointer (staging host memory on the ctx stream)
 int mrz_stage_input(mrz_ctx *ctx, const void *buf, int64_t n, int where, const uint8_t **dev);

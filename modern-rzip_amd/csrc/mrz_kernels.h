@@ -10,17 +10,28 @@ typedef unsigned long long mrz_u64;
 struct mrz_crc_tables;
 
 extern "C" {
-hipError_t mrz_launch_tagscan(hipStream_t stream, const uint8_t *buf, int64_t n, int64_t seg_start, int64_t seg_len,
-                              const int64_t *hash_index, const mrz_seq_state *st, int64_t *tags, uint16_t *bitmap16);
-hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
-                                const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st, int64_t seg_start,
-                                int64_t seg_len, void *gmailbox, int n_helpers, void *wide_shared, unsigned *wlog,
-                                int64_t nslots, int seq_wgs);
+// the front end's buffers for one pass (device memory): see mrz_tagscan.hip
+struct mrz_fe_bufs {
+    mrz_fe_hdr *hdr;
+    uint16_t *bitmap16;  // 16 pass bits per thread of a tile: 1 bit per position, bit 0 of word 0 = the pass's first position
+    int *tile_cnt;       // candidates per tile
+    int *tile_off;       // list offset of every tile (+ one entry: the total)
+    int *grp_cnt;        // candidates per group of MRZ_FE_GROUP tiles
+    mrz_cand *cand;      // the list
+};
+hipError_t mrz_launch_frontend(hipStream_t stream, const uint8_t *buf, int64_t n, const int64_t *hash_index,
+                               mrz_seq_state *st, int max_tiles, int64_t cap, mrz_fe_hdr *hdr, uint16_t *bitmap16,
+                               int *tile_cnt, int *tile_off, int *grp_cnt, mrz_cand *cand);
+// xcd: which of the 8 XCDs (block index mod 8 under round-robin placement) carries the sequencer workgroups
+hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
+                                const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
+                                void *gmailbox, int n_helpers, void *wide_shared, unsigned *wlog,
+                                int64_t nslots, int seq_wgs, int xcd);
 size_t mrz_sequencer_shared_size(void);
 size_t mrz_sequencer_wlog_size(int64_t nslots);
-hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
-                                       const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st, int64_t seg_start,
-                                       int64_t seg_len, void *gmailbox, int n_helpers);
+hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
+                                       const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
+                                       void *gmailbox, int n_helpers, int xcd);
 size_t mrz_sequencer_mailbox_size(void);
 size_t mrz_seq_narrow_mailbox_size(void);
 int mrz_sequencer_default_helpers(int device);

@@ -1,8 +1,10 @@
-// mrz_seq_common.h -- pieces shared by the two halves of the sequencer kernel (mrz_sequencer.hip):
-// the wave-wide compares of single_match_len, the compare farm (helper workgroups on the other CUs),
-// the matcher state, and the COOPERATIVE PATH: one candidate at a time, the whole of wave 0 on its probe
-// chain (any chain length, any match length, cascades, chain-limit evictions, sweep wrap, mask promotion).
-// The wide batch engine (mrz_seq_wide.h) falls back to it for whatever it cannot prove.
+// mrz_seq_common.h -- pieces shared by the two sequencer kernels (the wide engine of mrz_sequencer.hip /
+// mrz_seq_wide.h and the narrow engine of mrz_seq_narrow.hip): the candidate list's lower bound, the wave-wide
+// compares of single_match_len, the compare farm (helper workgroups on the other CUs), the matcher state, and the
+// COOPERATIVE PATH: one candidate at a time, the whole of wave 0 on its probe chain (any chain length, any match
+// length, cascades, chain-limit evictions, sweep wrap, mask promotion).  Both batch engines fall back to it for
+// whatever they cannot prove.  The narrow engine defines MRZ_NARROW_ENGINE (and its own MRZ_SEQ_WAVES) before
+// including this file: its workgroup stripes long forward extensions over a second wave through an LDS mailbox.
 #pragma once
 #include "mrz_device.h"
 #include <stdlib.h>
@@ -18,8 +20,16 @@
 #ifndef MRZ_WIDE_WAVES
 #define MRZ_WIDE_WAVES 8  // waves of the wide engine's workgroup = 64-lane slices of a wide batch
 #endif                    // (the CPU emulator build takes 2: 512 fibers per barrier are slow, the logic is the same)
+#ifndef MRZ_SEQ_WAVES
 #define MRZ_SEQ_WAVES MRZ_WIDE_WAVES
+#endif
 #define MRZ_SEQ_THREADS (64 * MRZ_SEQ_WAVES)
+// waves of the sequencer workgroup a long forward extension is striped over (narrow engine: leader + stripe helper)
+#ifdef MRZ_NARROW_ENGINE
+#define MRZ_STRIPE_WAVES (MRZ_SEQ_WAVES > 2 ? MRZ_SEQ_WAVES - 1 : MRZ_SEQ_WAVES)
+#else
+#define MRZ_STRIPE_WAVES 1
+#endif
 #ifndef MRZ_HELPER_WAVES
 #define MRZ_HELPER_WAVES 3  // waves of a helper workgroup that compare (the others leave at once)
 #endif
@@ -71,20 +81,51 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        MRZ_ST_T_SCAN, MRZ_ST_T_FOLD, MRZ_ST_T_COMMIT, MRZ_ST_REPREP, MRZ_ST_W_STALE, MRZ_ST_W_DROP, MRZ_ST_RESET,
        MRZ_ST_T_TURN, MRZ_ST_T_PREP, MRZ_ST_T_PRECOMMIT, MRZ_ST_E_MASK, MRZ_ST_E_CULL, MRZ_ST_E_XW, MRZ_ST_E_INWIN,
        MRZ_ST_E_WINDOW, MRZ_ST_E_BULK, MRZ_ST_E_MORE, MRZ_ST_T_PC_CW, MRZ_ST_T_PC_LOG, MRZ_ST_T_PC_BEST, MRZ_ST_T_PC_BULK, MRZ_ST_T_TURNWORK, MRZ_ST_T_SNAP, MRZ_ST_REBULK,
+       // (the narrow engine's own)
+       MRZ_ST_BATCH_LANES, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT, MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS,
+       MRZ_ST_CUT_CASCADE, MRZ_ST_BATCH_FORMED, MRZ_ST_T_WALK2, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_WINDOW,
        MRZ_ST_N };
+static_assert(MRZ_ST_N <= (int)(sizeof(((mrz_seq_state *)0)->prof) / sizeof(int64_t)), "mrz_seq_state.prof holds the counters");
 
 struct mrz_seq_args {
     const uint8_t *buf;
     mrz_slot *tab;
-    const int64_t *tags;      // dense tags of this segment
-    const mrz_u64 *bitmap;    // candidate bitmap of this segment (64 positions per word)
+    const mrz_cand *cand;     // the front end's candidate list of this segment: {position, tag}, position order
+    const int *tile_off;      // list offset of every 4096-position tile of the segment
+    const mrz_u64 *bitmap;    // pass bits of the segment, 64 positions per word (bit 0 of word 0 = st->seg_start)
     mrz_event *events;
-    mrz_seq_state *st;
-    int64_t seg_start;
-    int64_t seg_len;
+    mrz_seq_state *st;        // carries the segment's geometry: seg_start, seg_end, n_cand (mrz_tagscan.hip)
     void *gmailbox;           // mrz_gmailbox in device memory, zeroed by the host before every launch
-    int n_helpers;            // helper workgroups in this launch (grid size - 1)
+    int n_helpers;            // helper workgroups in this launch
+    int xcd;                  // block index mod 8 of the sequencer workgroups
 };
+
+// the candidate list of one segment, as the sequencers see it
+struct mrz_cands {
+    const mrz_cand *cand;
+    const int *tile_off;
+    const mrz_u64 *bitmap;
+    int64_t seg_start, seg_end, n;
+};
+
+// Index of the first list entry at or behind position `pos` (wave-wide, all lanes; one round trip): the tile's offset
+// plus the pass bits of the tile below `pos`.
+__device__ static int64_t mrz_cand_lower_bound(const mrz_cands &K, int64_t pos, int lane) {
+    if (pos <= K.seg_start) return 0;
+    if (pos >= K.seg_end) return K.n;
+    const int64_t rel = pos - K.seg_start;
+    const int64_t tile = rel >> MRZ_TILE_SHIFT;
+    const int r = (int)(rel & (MRZ_TILE - 1));
+    const mrz_u64 w = K.bitmap[tile * (MRZ_TILE / 64) + lane];
+    const int base = K.tile_off[tile];
+    int c = 0;
+    if (lane < (r >> 6))
+        c = __popcll(w);
+    else if (lane == (r >> 6))
+        c = __popcll(w & mrz_low_mask(r & 63));
+    const int sum = mrz_lane_read(mrz_wave_incl_sum(c, lane), 63);
+    return (int64_t)mrz_uni(base) + sum;
+}
 
 // workgroup-scope accesses to LDS control words
 __device__ __forceinline__ int mrz_mb_load(int *p) {
@@ -93,6 +134,23 @@ __device__ __forceinline__ int mrz_mb_load(int *p) {
 __device__ __forceinline__ void mrz_mb_store(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
+__device__ __forceinline__ void mrz_mb_add(int *p, int v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LDS mailbox between the narrow engine's leader and its helper waves: one long forward extension at a time, striped
+// over the waves of the workgroup; and the scout's hand-off words
+struct mrz_mailbox {
+    int64_t p0, op, maxf, base;     // compare buf[p0+x] with buf[op+x] for x in [base + wave*STRIPE, +STRIPE), x < maxf
+    int64_t res[MRZ_SEQ_WAVES];     // per wave: first stop offset of its stripe, or -1
+    int seq;                        // bumped by the leader for every round; helpers wait on it
+    int done;                       // helpers add 1 when their stripe is finished
+    int quit;
+    int scout_seq;                  // bumped whenever scout_pos changes
+    int64_t scout_pos;              // the leader's position: the scout warms the caches for what follows
+    int64_t scout_clean;            // tag_clean_ptr, for the cull sweep window
+};
 
 #ifndef MRZ_STRIPE_PIECES
 #define MRZ_STRIPE_PIECES 4
@@ -172,12 +230,14 @@ __device__ static int64_t mrz_wave_bwd(const uint8_t *__restrict__ buf, int64_t 
     }
 }
 
-// Long candidate on the leader wave alone: forward in 4 KiB rounds (64 lanes x 16 B x 4 pieces, ballot + ffs
-// for the first mismatch), backward once.  With `cont_base` the caller takes over after the first round that
-// finds no difference (the compare farm continues from there): returns -1.
-__device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, int64_t p0, int64_t op, int64_t end,
-                                             int64_t last_match, int64_t *rev_out, int lane, int64_t *stat = nullptr,
-                                             int64_t *cont_base = nullptr) {
+// Long candidate: forward in 4 KiB rounds per wave (64 lanes x 16 B x 4 pieces, ballot + ffs for the first mismatch),
+// backward once.  In the narrow engine's workgroup (mb != nullptr) the forward extension is striped over
+// MRZ_STRIPE_WAVES waves through the LDS mailbox: the leader folds the per-wave results and does the backward
+// extension while the helper is busy with the first round.  With `cont_base` the caller takes over after the first
+// round that finds no difference (the compare farm continues from there): returns -1.
+__device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, mrz_mailbox *mb, int *mb_seq, int64_t p0,
+                                             int64_t op, int64_t end, int64_t last_match, int64_t *rev_out, int lane,
+                                             int64_t *stat = nullptr, int64_t *cont_base = nullptr) {
     *rev_out = 0;
 #ifdef MRZ_SEQ_PROFILE
     int64_t lt0 = (int64_t)__builtin_amdgcn_s_memtime();
@@ -199,15 +259,34 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, in
     if (op < maxb) maxb = op;
     int64_t fwd = 0, rev = 0;
     bool have_rev = false;
+    const bool striped = MRZ_STRIPE_WAVES > 1 && mb != nullptr;
+    const int64_t round_bytes = (int64_t)(striped ? MRZ_STRIPE_WAVES : 1) * MRZ_STRIPE;
     if (maxf > 0) {
-        for (int64_t base = 0;; base += MRZ_STRIPE) {
-            const int64_t best = mrz_wave_fwd_stripe(buf, p0, op, maxf, base, lane);
+        for (int64_t base = 0;; base += round_bytes) {
+            if (striped) {
+                if (lane == 0) {
+                    mb->p0 = p0;
+                    mb->op = op;
+                    mb->maxf = maxf;
+                    mb->base = base;
+                    mb->done = 0;
+                }
+                *mb_seq += 1;
+                if (lane == 0) mrz_mb_store(&mb->seq, *mb_seq);
+            }
+            LPROF(MRZ_ST_L_POST);
+            int64_t best = mrz_wave_fwd_stripe(buf, p0, op, maxf, base, lane);  // the leader's own stripe (wave 0)
             LPROF(MRZ_ST_L_STRIPE);
             if (!have_rev) {
                 rev = mrz_wave_bwd(buf, p0, op, maxb, lane);
                 have_rev = true;
             }
             LPROF(MRZ_ST_L_BWD);
+            if (striped) {
+                while (mrz_uni(mrz_mb_load(&mb->done)) < MRZ_STRIPE_WAVES - 1) __builtin_amdgcn_s_sleep(1);
+                for (int w = 1; w < MRZ_STRIPE_WAVES && best < 0; w++) best = mrz_uni64(mb->res[w]);
+            }
+            LPROF(MRZ_ST_L_WAIT);
 #ifdef MRZ_SEQ_STATS
             if (stat) stat[MRZ_ST_L_ROUNDS] += 1;
 #endif
@@ -215,8 +294,8 @@ __device__ static int64_t mrz_long_match_len(const uint8_t *__restrict__ buf, in
                 fwd = best;
                 break;
             }
-            if (cont_base) {
-                *cont_base = base + MRZ_STRIPE;
+            if (cont_base) {  // the caller continues from here (compare farm); returns -1
+                *cont_base = base + round_bytes;
                 *rev_out = rev;
                 return -1;
             }
@@ -576,6 +655,8 @@ struct mrz_cfg {
     int n_helpers;             // helper workgroups in this launch
     int64_t *farm_hint;        // forward length of the last long match: go to the farm at once when it was big
     int *long_seen;            // set when a look-up had entries beyond the 64-byte reach (scheduling hint only)
+    mrz_mailbox *mb;           // narrow engine: LDS mailbox of its stripe helper wave (nullptr in the wide engine)
+    int *mb_seq;               // ... and the leader's copy of its round counter
 };
 
 // lazy selection + emission (src/rzip.c:586-599) for the candidate at L.p whose
@@ -817,7 +898,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_co
             if (!((longmask >> k) & 1)) continue;
             const int64_t op = mrz_bcast64(my_op, k);
             int64_t rv = 0, cont = 0;
-            int64_t ml = mrz_long_match_len(buf, qx, op, C.end, L.last_match, &rv, lane, stat,
+            int64_t ml = mrz_long_match_len(buf, C.mb, C.mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat,
 #if MRZ_HELPER_WGS > 0
                                             (C.gmb && *C.gnw >= MRZ_FARM_ENTRIES) ? &cont : nullptr
 #else
@@ -833,7 +914,7 @@ __device__ static bool mrz_resolve_entries(const mrz_cfg &C, mrz_lead &L, mrz_co
                     ml = fw + rv;
                     if (ml < MRZ_MIN_MATCH) ml = 0;
                 } else  // the farm gave up: all of it locally
-                    ml = mrz_long_match_len(buf, qx, op, C.end, L.last_match, &rv, lane, stat, nullptr);
+                    ml = mrz_long_match_len(buf, C.mb, C.mb_seq, qx, op, C.end, L.last_match, &rv, lane, stat, nullptr);
             }
 #endif
             if (lane == k) {

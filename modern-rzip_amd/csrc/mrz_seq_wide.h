@@ -5,9 +5,10 @@
 // single_match_len (:372-397).  A batch takes the next MRZ_W (= 64 x waves) candidates of the position stream,
 // ONE LANE PER CANDIDATE, and runs in phases, all waves of the workgroup together:
 //
-//   A  formation   the next candidates from the tag-scan bitmap (one 64-position word per thread, workgroup
-//                  prefix sum of the popcounts, rank -> position), their tags; the cull window: a bitmask of the
-//                  entries ahead of tag_clean_ptr that fail the next mask (clean_one_from_hash, :313-321);
+//   A  formation   the next entries of the front end's candidate list (a few per thread: the list was made under the
+//                  mask of a launch or two ago, the ones that still pass minimum_tag_mask are compacted into the
+//                  lanes); the cull window: a bitmask of the entries ahead of tag_clean_ptr that fail the next
+//                  mask (clean_one_from_hash, :313-321);
 //   B  walk        every lane walks its probe chain in the table AS IT STANDS (8 slots = one 128-B line per step,
 //                  long chains are finished by the lane's whole wave, 64 slots per step): first empty slot, the
 //                  tag-equal entries in probe order, where insert_hash's walk stops (empty / due-for-culling
@@ -78,11 +79,8 @@ struct mrz_wide_lds {
     unsigned long long hand[32];  // the hand-over block of mrz_wide_shared: loaded at a turn, stored at its end
     int64_t prep_min_mask, prep_tag_mask;  // the masks the batch was prepared under
     int64_t cw_base, w_end, floor_prep;
-    int64_t adv_to, scan_last;  // see mrz_wide_prep
+    int64_t adv_to;  // see mrz_wide_prep
     int cw_len;
-    // formation
-    int pref[MRZ_W];
-    mrz_u64 word[MRZ_W];
     // per-lane facts other lanes / waves need
     int64_t q[MRZ_W];
     int h[MRZ_W], len1[MRZ_W], h2[MRZ_W], len2[MRZ_W], wslot[MRZ_W], w2[MRZ_W];
@@ -830,18 +828,21 @@ struct mrz_wide_ret {
 #define MRZ_LF_LONG 16
 #define MRZ_LF_REVS 32   // some entry has equal bytes before it: its result depends on how close last_match is
 
-// PREPARATION of one wide batch (phases A-C): all threads of the workgroup.  The batch is a WINDOW OF POSITIONS
-// [win_start, win_start + win_len) of the segment (win_start on a bitmap word, win_len <= 64 x threads): its
-// candidates, at most MRZ_W of them, one lane each.  Nothing here depends on the matcher's moving state except the
-// two masks (min_mask decides who is a candidate, tag_mask who inserts) and the table itself -- which may be BEHIND:
-// when several sequencer workgroups take turns, a batch is prepared while earlier batches are still being committed,
-// and the pre-commit step checks every lane against the log of blocks written since (mrz_wide_precommit).
+#ifndef MRZ_RAW_PER_THREAD
+#define MRZ_RAW_PER_THREAD 4  // list entries a thread examines in the formation: a batch window holds at most 4 x threads
+#endif
+
+// PREPARATION of one wide batch (phases A-C): all threads of the workgroup.  The batch is a WINDOW OF THE CANDIDATE
+// LIST: entries [i0, i0 + pw) of the segment's list (pw <= MRZ_RAW_PER_THREAD x threads), of which those that still
+// pass min_mask -- at most MRZ_W of them -- get one lane each.  Nothing here depends on the matcher's moving state
+// except the two masks (min_mask decides who is a candidate, tag_mask who inserts) and the table itself -- which may
+// be BEHIND: when several sequencer workgroups take turns, a batch is prepared while earlier batches are still being
+// committed, and the pre-commit step checks every lane against the log of blocks written since (mrz_wide_precommit).
 // Leaves everything the commit needs in LDS; S->nb == 0 means the window held no candidate.
 template <int NW>
-__device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const int64_t *__restrict__ tags,
-                                     const mrz_u64 *__restrict__ bitmap, int64_t seg_start, int64_t lim, int64_t nwords,
-                                     int64_t win_start, int win_len, int64_t min_pos, int64_t min_mask, int64_t tag_mask,
-                                     int tid, int lane, int wave, int64_t *stat) {
+__device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const mrz_cands &K, int64_t lim, int64_t i0, int pw,
+                                     int64_t min_pos, int64_t min_mask, int64_t tag_mask, int tid, int lane, int wave,
+                                     int64_t *stat) {
     constexpr int WT = 64 * NW;  // threads (= lanes of the batch at most) taking part
     const uint8_t *__restrict__ buf = C.buf;
     const int smask = (int)C.slot_mask;
@@ -849,19 +850,30 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     PROF_T0();
 
     // ---- A: formation ----------------------------------------------------------------------------------
-    const int64_t w0 = (win_start - seg_start) >> 6;
-    const int64_t widx = w0 + tid;
-    mrz_u64 w = (tid * 64 < win_len && widx < nwords) ? bitmap[widx] : 0ull;
-    {
-        const int64_t lane_lo = seg_start + widx * 64;
-        if (lim < lane_lo + 63) {
-            const int64_t keepbits = lim - lane_lo + 1;
-            w = keepbits <= 0 ? 0ull : (w & mrz_low_mask((int)keepbits));
+    int nraw = (K.n - i0) < (int64_t)pw ? (int)(K.n - i0) : pw;
+    if (nraw > MRZ_RAW_PER_THREAD * WT) nraw = MRZ_RAW_PER_THREAD * WT;
+    int64_t qr[MRZ_RAW_PER_THREAD], tr[MRZ_RAW_PER_THREAD];
+    bool ar[MRZ_RAW_PER_THREAD];
+    int cnt_a = 0;
+#pragma unroll
+    for (int e = 0; e < MRZ_RAW_PER_THREAD; e++) {
+        const int r = MRZ_RAW_PER_THREAD * tid + e;
+        qr[e] = 0;
+        tr[e] = 0;
+        ar[e] = false;
+        if (r < nraw) {
+            const mrz_cand c = K.cand[i0 + r];
+            qr[e] = c.off;
+            tr[e] = c.t;
+            ar[e] = c.off >= min_pos && c.off <= lim && (c.t & min_mask) == min_mask;
         }
-        if (min_pos > lane_lo) {  // the epoch begins inside this word
-            const int64_t drop = min_pos - lane_lo;
-            w = drop >= 64 ? 0ull : (w & ~mrz_low_mask((int)drop));
-        }
+        cnt_a += ar[e] ? 1 : 0;
+    }
+    // where the window ends: just before the first entry of the next one
+    int64_t wend = lim;
+    if (tid == 0 && i0 + nraw < K.n) {
+        const int64_t nx = K.cand[i0 + nraw].off - 1;
+        wend = nx < lim ? nx : lim;
     }
     for (int i = tid; i < MRZ_BH_SIZE; i += WT) {
         S->bh_key[i] = 0u;
@@ -883,63 +895,29 @@ __device__ static void mrz_wide_prep(const mrz_cfg &C, mrz_wide_lds *S, const in
     S->supp_w2[tid] = (unsigned short)MRZ_W;
     const int64_t cw_base = 0;  // the cull window is the pre-commit step's business
     const int cw_len = 0;
-    const int cnt = __popcll(w);
-    int total_raw;
-    const int incl = mrz_wide_incl<NW>(cnt, S->wt1, lane, wave, &total_raw);
-    S->pref[tid] = incl - cnt;
-    S->word[tid] = w;
-    mrz_prep_sync<NW>();
-    // The bitmap was made under the mask of the time of the tag scan (a launch or two ago): some of its candidates no
-    // longer pass min_mask.  Every thread examines two of them (neighbours, so that the order stays the positions'),
-    // the ones that pass are compacted into the lanes.
-    const int raw_cap = 2 * WT;
-    const int nraw = total_raw < raw_cap ? total_raw : raw_cap;
-    int64_t qr[2] = { 0, 0 }, tr[2] = { 0, 0 };
-    bool ar[2] = { false, false };
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int r = 2 * tid + e;
-        int wlo = 0, whi = WT - 1;
-        for (int it = 0; (1 << it) < WT; it++) {
-            const int mid = (wlo + whi + 1) >> 1;
-            if (S->pref[mid] <= r)
-                wlo = mid;
-            else
-                whi = mid - 1;
-        }
-        if (r < nraw) {
-            qr[e] = seg_start + (w0 + wlo) * 64 + mrz_select64(S->word[wlo], r - S->pref[wlo]);
-            tr[e] = tags[qr[e] - seg_start];
-            ar[e] = (tr[e] & min_mask) == min_mask;
-            if (r == nraw - 1) S->scan_last = qr[e];
-        }
-    }
     int total;
-    const int cnt_a = (ar[0] ? 1 : 0) + (ar[1] ? 1 : 0);
     const int incl_a = mrz_wide_incl<NW>(cnt_a, S->wt3, lane, wave, &total);
     {
-        const int base = incl_a - cnt_a;
-        if (ar[0] && base < MRZ_W) {
-            S->q[base] = qr[0];
-            S->t[base] = tr[0];
-        }
-        const int b1 = base + (ar[0] ? 1 : 0);
-        if (ar[1] && b1 < MRZ_W) {
-            S->q[b1] = qr[1];
-            S->t[b1] = tr[1];
-        }
+        int at = incl_a - cnt_a;
+#pragma unroll
+        for (int e = 0; e < MRZ_RAW_PER_THREAD; e++)
+            if (ar[e]) {
+                if (at < MRZ_W) {
+                    S->q[at] = qr[e];
+                    S->t[at] = tr[e];
+                }
+                at++;
+            }
     }
     const int nb = total < MRZ_W ? total : MRZ_W;
     mrz_prep_sync<NW>();
     if (tid == 0) {
-        const int64_t wend0 = win_start + win_len - 1;
-        const int64_t wend = wend0 < lim ? wend0 : lim;
         S->nb = nb;
         S->total = total;  // > nb: more candidates than a batch has lanes
         S->w_end = wend;
         // how far the matcher may move once every lane has been committed: nowhere beyond the last lane when candidates
-        // were left out, to the last one examined when the window held more than could be examined, else to its end
-        S->adv_to = total > MRZ_W ? (int64_t)-1 : (total_raw > raw_cap ? S->scan_last : wend);
+        // were left out, else to the window's end
+        S->adv_to = total > MRZ_W ? (int64_t)-1 : wend;
         S->prep_min_mask = min_mask;
         S->prep_tag_mask = tag_mask;
     }

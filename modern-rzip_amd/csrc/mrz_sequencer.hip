@@ -5,12 +5,12 @@
 // in-place culling without tombstones :305-328, the process-lifetime victim_round :259), so it has to be
 // replayed in position order to stay bit-exact.  What the GPU changes is the width of every step.
 //
-// Grid: blocks 0, 8, 16, ... (up to MRZ_SEQ_WGS of them; one XCD under round-robin placement, checked at run time)
-// are SEQUENCER workgroups of MRZ_SEQ_WAVES waves (512 threads); the other blocks are the helper workgroups of the
+// Grid: blocks x, x + 8, x + 16, ... (x = the launch's XCD residue; up to MRZ_SEQ_WGS of them; one XCD under round-robin
+// placement, checked at run time) are SEQUENCER workgroups of MRZ_SEQ_WAVES waves (512 threads); the other blocks are the helper workgroups of the
 // compare farm (mrz_seq_common.h).  The sequencer workgroups run the WIDE BATCH ENGINE (mrz_seq_wide.h) and take
 // turns:
 //
-//   * batches are fixed windows of positions; a workgroup PREPARES its batch -- probe walks, conflicts inside the
+//   * batches are fixed windows of the front end's candidate list; a workgroup PREPARES its batch -- probe walks, conflicts inside the
 //     batch, overlay walks, 64-byte match probes, all read-only -- while the batches before it are being committed;
 //   * at its TURN (a token in device memory) it loads the matcher state, brings the prepared lanes up to date
 //     (lanes a match has covered since, table blocks written since: the write log; the cull window), commits in
@@ -53,7 +53,7 @@ extern __device__ unsigned *mrz_dbg_hits;
 #define MRZ_TURN_SPIN_LIMIT (1ll << 27)
 
 // words of mrz_wide_shared.hand: the matcher state (mrz_lead, 16 words) and what goes with it
-enum { MRZ_H_L = 0, MRZ_H_GSEQ = 16, MRZ_H_FARM, MRZ_H_GNW, MRZ_H_PW, MRZ_H_SMALL, MRZ_H_EPOCH, MRZ_H_BWORD, MRZ_H_BBATCH,
+enum { MRZ_H_L = 0, MRZ_H_GSEQ = 16, MRZ_H_FARM, MRZ_H_GNW, MRZ_H_PW, MRZ_H_SMALL, MRZ_H_EPOCH, MRZ_H_BIDX, MRZ_H_BBATCH,
        MRZ_H_BPOS, MRZ_H_N = 32 };
 static_assert(sizeof(mrz_lead) == 16 * 8, "mrz_lead is handed over as 16 words");
 
@@ -69,9 +69,9 @@ struct mrz_wide_shared {          // device memory, zeroed by the host before ev
     // two lines handed from committer to committer: written by ONE store instruction of the committing wave (a word
     // per lane, agent scope) before it passes the token on, read by ONE agent-scope load instruction of the next
     // committer after it has seen the token -- served by the L2, never by a line some earlier load left in an L1.
-    //   [0, 16)  mrz_lead    [16] farm round counter   [17] farm hint   [18] helpers seen   [19] pw: bitmap words per
-    //   batch window   [20] batches in a row that came out less than half full   [21] epoch   [22] base_word
-    //   [23] base_batch: batch b of the epoch covers words [base_word + (b - base_batch) * pw, + pw)   [24] base_pos:
+    //   [0, 16)  mrz_lead    [16] farm round counter   [17] farm hint   [18] helpers seen   [19] pw: list entries per
+    //   batch window   [20] batches in a row that came out less than half full   [21] epoch   [22] base_idx
+    //   [23] base_batch: batch b of the epoch covers list entries [base_idx + (b - base_batch) * pw, + pw)   [24] base_pos:
     //   ... and nothing before this position (where the epoch began)
     unsigned long long hand[MRZ_H_N];
 };
@@ -90,13 +90,13 @@ static_assert(offsetof(mrz_wide_shared, hand) == 128, "the hand-over block has i
 #define MRZ_XCC_ID() 0
 #endif
 
-__device__ __forceinline__ int mrz_words_per_batch(int64_t min_mask) {
-    // candidates are 2^-k of the positions (k mask bits): aim at 7/8 of the lanes, whole bitmap words
-    const int k = __popcll((unsigned long long)min_mask);
-    long long pos = (long long)(MRZ_W * MRZ_FILL_NUM / 16) << (k < 20 ? k : 20);
-    long long wds = pos / 64;
-    if (wds > MRZ_W) wds = MRZ_W;
-    return (int)(wds < 1 ? 1 : wds);
+__device__ __forceinline__ int mrz_entries_per_batch(int64_t list_mask, int64_t min_mask) {
+    // the list holds the positions that passed list_mask; 2^-(k - kl) of them still pass min_mask: aim at 7/8 of the lanes
+    int d = __popcll((unsigned long long)min_mask) - __popcll((unsigned long long)list_mask);
+    if (d < 0) d = 0;
+    long long ent = (long long)(MRZ_W * MRZ_FILL_NUM / 16) << (d < 8 ? d : 8);
+    if (ent > MRZ_RAW_PER_THREAD * MRZ_W) ent = MRZ_RAW_PER_THREAD * MRZ_W;
+    return (int)(ent < 1 ? 1 : ent);
 }
 
 __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_args a, mrz_wide_shared *G,
@@ -122,9 +122,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     if (st->finished || st->error) return;
     // which role: blocks 0, 8, 16, ... are sequencer workgroups (one XCD), the others compare-farm helpers
     int wgs = want_wgs < 1 ? 1 : (want_wgs > MRZ_SEQ_WGS ? MRZ_SEQ_WGS : want_wgs);
-    while (wgs > 1 && (int)gridDim.x < 8 * (wgs - 1) + 1) wgs--;
     const int bx = (int)blockIdx.x;
-    const bool is_seq = (bx % 8 == 0) && (bx / 8 < wgs);
+    const int xcd = a.xcd & 7;
+    while (wgs > 1 && (int)gridDim.x < 8 * (wgs - 1) + xcd + 1) wgs--;
+    const bool is_seq = (bx % 8 == xcd) && (bx / 8 < wgs) && (bx < (int)gridDim.x);
 #if MRZ_HELPER_WGS > 0
     if (!is_seq) {
         if (a.gmailbox) mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);  // (no mailbox: a launch without a farm)
@@ -156,10 +157,20 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
     C.farm_hint = &farm_hint;
     int long_seen = 0;
     C.long_seen = &long_seen;
-    const int64_t seg_start = a.seg_start;
-    const int64_t seg_end = a.seg_start + a.seg_len;
+    C.mb = nullptr;
+    C.mb_seq = nullptr;
+    mrz_cands K;  // the segment the front end has laid out: its geometry comes with the matcher state
+    K.cand = a.cand;
+    K.tile_off = a.tile_off;
+    K.bitmap = a.bitmap;
+    K.seg_start = st->seg_start;
+    K.seg_end = st->seg_end;
+    K.n = st->n_cand;
+    const int64_t seg_start = K.seg_start;
+    const int64_t seg_end = K.seg_end;
+    if (seg_end <= seg_start) return;  // (nothing was scanned: the chunk is done)
     const int64_t lim = (C.end < seg_end - 1) ? C.end : seg_end - 1;  // last candidate position of this launch
-    const int64_t nwords = (a.seg_len + 63) / 64;
+    const int64_t list_mask = st->list_mask;
 #ifdef MRZ_SEQ_STATS
     int64_t stat[MRZ_ST_N];
     for (int k = 0; k < MRZ_ST_N; k++) stat[k] = 0;
@@ -175,9 +186,9 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             __hip_atomic_fetch_add(&G->census, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (j == 0) {
-        if (tid == 0) {
-            int n = 1;
+    if (j == 0 && wave == 0) {
+        int n = 1;
+        if (lane == 0) {
             if (wgs > 1) {
                 long long spins = 0;  // the others start within microseconds; late ones are left out
                 while (__hip_atomic_load(&G->census, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)wgs &&
@@ -192,7 +203,12 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 }
             } else
                 G->active[0] = 0;
-            // the matcher state, the first epoch
+        }
+        // the matcher state, the first epoch: the list from the first entry behind the matcher's position
+        int64_t pos = st->p + 1;
+        if (pos < seg_start) pos = seg_start;
+        const int64_t bidx = mrz_cand_lower_bound(K, pos, lane);
+        if (lane == 0) {
             mrz_lead L;
             L.p = st->p;
             L.cur_p = st->cur_p;
@@ -211,15 +227,13 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             L.last_len = 0;
             L.mbytes = 0;
             *(mrz_lead *)&S->hand[MRZ_H_L] = L;
-            int64_t pos = L.p + 1;
-            if (pos < seg_start) pos = seg_start;
             S->hand[MRZ_H_GSEQ] = 0;
             S->hand[MRZ_H_FARM] = 0;
             S->hand[MRZ_H_GNW] = 0;
-            S->hand[MRZ_H_PW] = (unsigned long long)mrz_words_per_batch(L.min_mask);
+            S->hand[MRZ_H_PW] = (unsigned long long)mrz_entries_per_batch(list_mask, L.min_mask);
             S->hand[MRZ_H_SMALL] = 0;
             S->hand[MRZ_H_EPOCH] = 1;
-            S->hand[MRZ_H_BWORD] = (unsigned long long)((pos - seg_start) >> 6);
+            S->hand[MRZ_H_BIDX] = (unsigned long long)bidx;
             S->hand[MRZ_H_BBATCH] = 0;
             S->hand[MRZ_H_BPOS] = (unsigned long long)pos;
             for (int k = 0; k <= MRZ_H_BPOS; k++)
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             for (int tries = 0; tries < 64; tries++) {
                 t0 = __hip_atomic_load(&G->token, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 e = (long long)__hip_atomic_load(&G->hand[MRZ_H_EPOCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bw = (long long)__hip_atomic_load(&G->hand[MRZ_H_BWORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bw = (long long)__hip_atomic_load(&G->hand[MRZ_H_BIDX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bb = (long long)__hip_atomic_load(&G->hand[MRZ_H_BBATCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bp = (long long)__hip_atomic_load(&G->hand[MRZ_H_BPOS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pw = (int)__hip_atomic_load(&G->hand[MRZ_H_PW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -281,20 +295,16 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         if (S->snap64[7]) break;
         unsigned snap = (unsigned)S->snap64[0];
         long long epoch = S->snap64[1];
-        long long base_word = S->snap64[2], base_batch = S->snap64[3];
+        long long base_idx = S->snap64[2], base_batch = S->snap64[3];
         int pw = (int)S->snap64[4];
         long long p_min = S->snap64[5], p_tag = S->snap64[6], base_pos = S->snap64[8];
         __syncthreads();
-        int64_t win_start = 0;
-        int win_len = 0;
+        int64_t i0 = 0;  // this batch's window of the candidate list: entries [i0, i0 + pw)
         PROF_T0();
         bool have_prep = (long long)b >= base_batch;
         if (have_prep) {
-            win_start = seg_start + (base_word + ((long long)b - base_batch) * pw) * 64;
-            win_len = pw * 64;
-            if (win_start <= lim)
-                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, a.tags, a.bitmap, seg_start, lim, nwords, win_start, win_len, base_pos, p_min,
-                                             p_tag, tid, lane, wave, stat);
+            i0 = base_idx + ((long long)b - base_batch) * pw;
+            if (i0 < K.n) mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, K, lim, i0, pw, base_pos, p_min, p_tag, tid, lane, wave, stat);
         }
 
         PROF_ADD(MRZ_ST_T_PREP);
@@ -352,22 +362,20 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
         if (cur_epoch != epoch || !have_prep || L.min_mask != p_min || L.tag_mask != p_tag) {
             // prepared under an older epoch (or not at all): once more, now that everything before it is committed
             epoch = cur_epoch;
-            base_word = (long long)S->hand[MRZ_H_BWORD];
+            base_idx = (long long)S->hand[MRZ_H_BIDX];
             base_batch = (long long)S->hand[MRZ_H_BBATCH];
             base_pos = (long long)S->hand[MRZ_H_BPOS];
             pw = (int)S->hand[MRZ_H_PW];
             snap = (unsigned)b;
-            win_start = seg_start + (base_word + ((long long)b - base_batch) * pw) * 64;
-            win_len = pw * 64;
+            i0 = base_idx + ((long long)b - base_batch) * pw;
             __syncthreads();
-            if (win_start <= lim)
-                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, a.tags, a.bitmap, seg_start, lim, nwords, win_start, win_len, base_pos,
-                                             L.min_mask, L.tag_mask, tid, lane, wave, stat);
+            if (i0 < K.n)
+                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, K, lim, i0, pw, base_pos, L.min_mask, L.tag_mask, tid, lane, wave, stat);
         }
         bool finish = false;
         int passed_on = 0;  // the committing wave has handed state and token on already
-        if (win_start > lim) {
-            // the segment is done: nothing but the end is left
+        if (i0 >= K.n) {
+            // the segment's list is used up: nothing but the end is left
             if (L.p < lim) L.p = lim;
             finish = true;
         } else {
@@ -402,27 +410,35 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                             const bool all_lanes = r.whole && !r.stop_batch;
                             if (all_lanes && adv_to > L.p) L.p = adv_to;  // no candidate is left up to there
                             const bool window_done = all_lanes && adv_to == w_end;
-                            const bool far = L.p > w_end + (int64_t)n_act * win_len;
-                            // the window size follows what the windows turn out to hold (the bitmap's density is not the mask's)
+                            // a match has carried the matcher beyond the windows prepared ahead: their turns would be wasted
+                            bool far = false;
+                            if (L.p > w_end) {
+                                int64_t ix = i0 + (int64_t)(n_act + 1) * pw;  // first entry behind those windows
+                                if (ix > K.n) ix = K.n;
+                                if (ix > i0 + pw) far = L.p >= mrz_uni64(K.cand[ix - 1].off);
+                            }
+                            // the window size follows what the windows turn out to hold (the list was made under an older mask)
+                            constexpr int MAXPW = MRZ_RAW_PER_THREAD * MRZ_W;
                             int new_pw = 0;
                             if (rounds == 0 && all_lanes) {
-                                if (!window_done)
-                                    new_pw = total > MRZ_W ? pw * 3 / 4 : pw / 2;  // too many: candidates, or bits to examine
-                                else if (total < MRZ_W * 3 / 8 && pw < MRZ_W) {
+                                if (!window_done)  // more candidates than lanes
+                                    new_pw = (int)((long long)pw * (MRZ_W * 3 / 4) / (total > MRZ_W ? total : MRZ_W));
+                                else if (total < MRZ_W * 3 / 8 && pw < MAXPW && i0 + pw <= K.n) {
                                     const int small = mrz_uni((int)S->hand[MRZ_H_SMALL]) + 1;
                                     MRZ_WAVE_SYNC();
                                     if (lane == 0) S->hand[MRZ_H_SMALL] = (unsigned long long)(small >= 4 ? 0 : small);
                                     if (small >= 4) new_pw = (int)((long long)pw * (MRZ_W * 3 / 4) / (total > 16 ? total : 16));
                                 } else if (lane == 0)
                                     S->hand[MRZ_H_SMALL] = 0;
-                                if (new_pw > MRZ_W) new_pw = MRZ_W;
+                                if (new_pw > MAXPW) new_pw = MAXPW;
                                 if (new_pw < 1 && new_pw != 0) new_pw = 1;
                                 if (new_pw == pw) new_pw = 0;
                             }
                             int verdict2 = 0;  // 0: pass the token on; 1: go on inside this window; 2: new epoch
-                            if (!r.ok || rounds > 2 * MRZ_W)
+                            if (!r.ok || rounds > 2 * MRZ_W) {
                                 verdict2 = 0;
-                            else if (masks_moved || far || L.p + 1 < win_start || new_pw > 0)
+                                if (r.ok && lane == 0) C.st->error = 6;  // (cannot happen: every round commits or drops a lane)
+                            } else if (masks_moved || far || new_pw > 0)
                                 verdict2 = 2;
                             else if (window_done || L.p >= w_end)
                                 verdict2 = 0;
@@ -435,16 +451,17 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                             ST_ADD(MRZ_ST_E_MORE, (all_lanes && !window_done) ? 1 : 0);
                             ST_ADD(MRZ_ST_RESET, verdict2 == 2 ? 1 : 0);
                             ST_ADD(MRZ_ST_REPREP, verdict2 == 1 ? 1 : 0);
+                            int64_t nb_pos = L.p + 1, nb_idx = 0;  // a new epoch begins at the first entry behind the matcher
+                            if (nb_pos < seg_start) nb_pos = seg_start;
+                            if (verdict2 == 2) nb_idx = mrz_cand_lower_bound(K, nb_pos, lane);
                             if (lane == 0) {
                                 if (verdict2 == 2) {
-                                    int64_t pos = L.p + 1;
-                                    if (pos < seg_start) pos = seg_start;
                                     S->hand[MRZ_H_EPOCH] = (unsigned long long)(cur_epoch + 1);
-                                    S->hand[MRZ_H_BWORD] = (unsigned long long)((pos - seg_start) >> 6);
-                                    S->hand[MRZ_H_BPOS] = (unsigned long long)pos;
+                                    S->hand[MRZ_H_BIDX] = (unsigned long long)nb_idx;
+                                    S->hand[MRZ_H_BPOS] = (unsigned long long)nb_pos;
                                     S->hand[MRZ_H_BBATCH] = b + 1;
-                                    S->hand[MRZ_H_PW] =
-                                        (unsigned long long)(masks_moved ? mrz_words_per_batch(L.min_mask) : (new_pw > 0 ? new_pw : pw));
+                                    S->hand[MRZ_H_PW] = (unsigned long long)(masks_moved ? mrz_entries_per_batch(list_mask, L.min_mask)
+                                                                                          : (new_pw > 0 ? new_pw : pw));
                                 }
                                 S->ctl[3] = ((r.ok && rounds <= 2 * MRZ_W) ? 0 : 1) | (finish ? 2 : 0) | (verdict2 == 1 ? 4 : 0);
                                 S->lead = L;
@@ -486,8 +503,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 if (wave != 0) L = S->lead;
                 snap = (unsigned)b;
                 __syncthreads();
-                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, a.tags, a.bitmap, seg_start, lim, nwords, win_start, win_len, L.p + 1,
-                                             L.min_mask, L.tag_mask, tid, lane, wave, stat);
+                mrz_wide_prep<MRZ_SEQ_WAVES>(C, S, K, lim, i0, pw, L.p + 1, L.min_mask, L.tag_mask, tid, lane, wave, stat);
             }
         }
         // ---- hand the state on (unless the committing wave has done so already) -----------------------------------
@@ -555,20 +571,20 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 }
 
 extern "C" size_t mrz_sequencer_wlog_size(int64_t nslots);
-extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const int64_t *tags,
-                                           const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
-                                           int64_t seg_start, int64_t seg_len, void *gmailbox, int n_helpers,
-                                           void *wide_shared, unsigned *wlog, int64_t nslots, int seq_wgs) {
+extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
+                                           const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
+                                           void *gmailbox, int n_helpers, void *wide_shared, unsigned *wlog, int64_t nslots,
+                                           int seq_wgs, int xcd) {
     mrz_seq_args a;
     a.buf = buf;
     a.tab = tab;
-    a.tags = tags;
+    a.cand = cand;
+    a.tile_off = tile_off;
     a.bitmap = bitmap;
     a.events = events;
     a.st = st;
-    a.seg_start = seg_start;
-    a.seg_len = seg_len;
     a.gmailbox = gmailbox;
+    a.xcd = xcd & 7;
 #if MRZ_HELPER_WGS == 0
     n_helpers = 0;
 #endif
@@ -582,9 +598,9 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     if (e == hipSuccess) e = hipMemsetAsync(wide_shared, 0, sizeof(mrz_wide_shared), stream);
     if (e == hipSuccess) e = hipMemsetAsync(wlog, 0, (size_t)mrz_sequencer_wlog_size(nslots), stream);
     if (e != hipSuccess) return e;
-    // blocks 0, 8, 16, ... are the sequencer workgroups (one XCD), the rest helpers: enough blocks for both
+    // blocks xcd, xcd + 8, xcd + 16, ... are the sequencer workgroups (one XCD), the rest helpers: enough blocks for both
     unsigned grid = (unsigned)(seq_wgs + a.n_helpers);
-    if (grid < (unsigned)(8 * (seq_wgs - 1) + 1)) grid = (unsigned)(8 * (seq_wgs - 1) + 1);
+    if (grid < (unsigned)(8 * (seq_wgs - 1) + a.xcd + 1)) grid = (unsigned)(8 * (seq_wgs - 1) + a.xcd + 1);
 #ifdef MRZ_EMU_LDS_PER_BLOCK
     emu::request_coresident();  // (test emulator: this kernel's workgroups wait for each other)
 #endif

@@ -15,8 +15,9 @@ What shards in the reference's path:
 
 * **one window over several GPUs** (`-U`, BASELINE configs[3]) -- the front end shards by byte
   range: every rank scans the tags of the segments inside its range (31-byte window: a 30-byte
-  halo) and ships them to the rank that runs the exact matcher, which takes them instead of
-  scanning (mrz_set_tag_provider); CRC-32 is checksummed per range and combined over GF(2).
+  halo), compacts the candidates (positions whose tag passes the matcher's mask) into 16-byte
+  records and ships those to the rank that runs the exact matcher, which takes them instead of
+  scanning (mrz_set_cand_provider); CRC-32 is checksummed per range and combined over GF(2).
   The matcher itself -- one dependency chain through the hash table -- does not shard; see
   rzip_chunk_window below and DESIGN.md section 6 for what this scales and what it does not.
 
@@ -206,87 +207,147 @@ def chunk_crc_sharded(data, rank, world, crc32_of, dist=None):
     return crc
 
 
-# ---- ONE window over several ranks: range-sharded tag scan, matcher on rank 0 (SURVEY.md 8e, configs[3]) --------
-def segment_ranges(total, world, seg_positions):
-    """Byte range of every rank, made of whole segments (so that every segment has one owner): [(offset, size)]."""
-    nseg = max(1, -(-max(total - 30, 1) // seg_positions))  # positions 0 .. total - 31 have a tag (end inclusive)
-    per = -(-nseg // world)
+# ---- ONE window over several ranks: range-sharded front end, matcher on rank 0 (SURVEY.md 8e, configs[3]) --------
+TILE = 4096  # positions per front-end tile: ranges are made of whole tiles
+
+
+def window_ranges(total, world, align=TILE):
+    """Byte range of every rank: contiguous, whole multiples of `align` bytes (the last one ends with the window):
+    [(offset, size)] * world (sizes may be 0)."""
+    per = -(-total // world)
+    per = -(-per // align) * align
     out = []
     for r in range(world):
-        off = min(r * per * seg_positions, total)
-        out.append((off, min(per * seg_positions, total - off)))
+        off = min(r * per, total)
+        out.append((off, min(per, total - off)))
     return out
 
 
-def rzip_chunk_window(ctx, my_bytes, my_off, total, rank, world, dist, seg_positions, victim_round=0, gather_bytes=True,
-                      scan_ctx=None):
-    """One chunk (window) of `total` bytes whose byte ranges live on the ranks: `my_bytes` = this rank's range
-    [my_off, my_off + len) of segment_ranges() plus up to 48 bytes of halo from the next rank.
-
-    Every segment's tags and candidate bitmap are computed by the rank that owns its bytes (ctx.window_scan) with the
-    minimum_tag_mask the matcher reported last, and sent to rank 0 (point-to-point; RCCL send/recv between GPUs, gloo
-    in the CPU test); rank 0 runs the exact matcher over them (ctx.rzip_chunk with a tag provider).  For the match
-    extension rank 0 reads the chunk's bytes: on one node through peer mappings of the other GPUs' ranges; in this
-    rehearsal the ranges are gathered to rank 0 first (gather_bytes).  scan_ctx: the context rank 0 scans its OWN
-    range with (a second one: `ctx` is busy with the chunk); made on demand.  Returns (ChunkResult, s0, s1) on rank 0.
-    """
+def _tensor_of(buf, dtype, device):
     import torch
-    ranges = segment_ranges(total, world, seg_positions)
-    owner_of = lambda seg_start: max(r for r in range(world) if ranges[r][0] <= seg_start and (ranges[r][1] or r == 0))
-    ctx.set_segment_positions(seg_positions)
+    t = torch.frombuffer(bytearray(buf), dtype=dtype) if len(buf) else torch.empty(0, dtype=dtype)
+    return t.to(device) if device is not None else t
 
+
+def rzip_chunk_window(ctx, my_bytes, my_off, total, rank, world, dist, victim_round=0, window=None, scan_ctx=None,
+                      device=None, cap=None, ranges=None):
+    """One chunk (window) of `total` bytes whose byte ranges live on the ranks: `my_bytes` = this rank's range
+    [my_off, my_off + len) of window_ranges() plus up to 48 bytes of halo from the next rank (bytes, or a cuda uint8
+    tensor that stays on the device).
+
+    The exact matcher runs on rank 0 (ctx.rzip_chunk with a candidate provider).  For every stretch of the window it is
+    about to sequence it asks the rank that owns the stretch's first position for ONE front-end pass
+    (ctx.window_scan: the candidates -- positions whose tag passes the minimum_tag_mask the matcher has last reported --
+    compacted into 16-byte {position, tag} records, plus the tile offsets and the pass bitmap that index the list) and
+    receives the result point-to-point: header [scan_next, n_cand], the records, the offsets, the bitmap.  `device`:
+    a torch device -- every message is then a DEVICE tensor (RCCL send/recv moves it GPU to GPU, the scan writes its
+    outputs straight into the send buffers, the matcher takes them by a device-to-device copy); None: CPU tensors (gloo).
+    A request with seg_start < 0 ends the service loops.
+
+    `window`: what rank 0 reads the window's bytes from for the match extension -- bytes / a cuda tensor / a
+    (device pointer, nbytes) pair covering all `total` bytes (e.g. a peer mapping of the other ranks' ranges,
+    window_map below).  None: the ranges are gathered to rank 0 first (a rehearsal: caps the window at one GPU's HBM).
+    scan_ctx: the context rank 0 scans its OWN range with (a second one: `ctx` is busy with the chunk); made on demand.
+    Returns (ChunkResult, s0, s1) on rank 0, None elsewhere."""
+    import torch
+    ranges = ranges or window_ranges(total, world)
+    starts = [r[0] for r in ranges]
+
+    def owner_of(pos):
+        own = 0
+        for r in range(world):
+            if ranges[r][1] > 0 and starts[r] <= pos:
+                own = r
+        return own
+
+    cap = cap or (1 << 20)
     own_scan_ctx = None
     if rank == 0 and scan_ctx is None:
         from .binding import RzipContext
         scan_ctx = own_scan_ctx = RzipContext(level=ctx.level, max_chunk=0, device=ctx.device, lib=ctx.lib)
     sc = scan_ctx if rank == 0 else (scan_ctx or ctx)
+    max_span = max(TILE, -(-max(r[1] for r in ranges) // TILE) * TILE)
+    tiles = max_span // TILE
+    bufs = None
+    if device is not None:  # the scan's outputs = the send buffers, on the device
+        bufs = (torch.empty(cap * 16, dtype=torch.uint8, device=device),
+                torch.empty((tiles + 1) * 4, dtype=torch.uint8, device=device),
+                torch.empty(tiles * (TILE // 8), dtype=torch.uint8, device=device))
 
-    def scan(seg_start, seg_len, min_mask, p_done):
-        return sc.window_scan(my_bytes, my_off, total, seg_start, seg_len, min_mask, p_done)
+    def scan(seg_start, span, min_mask, p_done, capx):
+        return sc.window_scan(my_bytes, my_off, total, seg_start, span, min_mask, p_done, cap=capx, out=bufs)
 
+    def clip(seg_start, span):  # the part of a stretch that lies in the range of the rank owning its first position
+        own = owner_of(seg_start)
+        r_end = ranges[own][0] + ranges[own][1]
+        if own == world - 1 or r_end >= total:
+            r_end = -(-total // TILE) * TILE
+        return own, max(TILE, min(span, r_end - seg_start, max_span))
+
+    hdr_dev = device if device is not None else "cpu"
     if rank == 0:
-        if world > 1 and gather_bytes:
-            parts = [None] * world
-            dist.gather_object(bytes(my_bytes[:ranges[0][1]]), parts, dst=0)
-            chunk = b"".join(parts)
-        else:
-            chunk = bytes(my_bytes[:total])
-        assert len(chunk) == total
+        if window is None:
+            mine = bytes(my_bytes[:ranges[0][1]].cpu().numpy().tobytes()) if hasattr(my_bytes, "data_ptr") else bytes(my_bytes[:ranges[0][1]])
+            if world > 1:
+                parts = [None] * world
+                dist.gather_object(mine, parts, dst=0)
+                window = b"".join(parts)
+            else:
+                window = mine
+        served = {"n": 0, "remote": 0, "bytes": 0}
 
-        def provider(seg_index, seg_start, seg_len, min_mask, p_done):
-            own = owner_of(seg_start)
-            if world > 1:  # tell everybody which segment is next (segments an emitted match has covered are skipped)
-                dist.broadcast(torch.tensor([seg_index, seg_start, seg_len, min_mask, p_done], dtype=torch.int64), src=0)
+        def provider(seg_start, span, min_mask, p_done, capx):
+            capx = min(capx, cap)
+            own, span = clip(seg_start, span)
+            served["n"] += 1
             if own == 0:
-                return scan(seg_start, seg_len, min_mask, p_done)
-            tags = torch.empty(seg_len, dtype=torch.int64)
-            bitmap = torch.empty((seg_len + 63) // 64, dtype=torch.int64)
-            dist.recv(tags, src=own)
-            dist.recv(bitmap, src=own)
-            return tags.numpy().tobytes(), bitmap.numpy().tobytes()
+                return scan(seg_start, span, min_mask, p_done, capx)
+            served["remote"] += 1
+            dist.send(torch.tensor([seg_start, span, min_mask, p_done, capx], dtype=torch.int64, device=hdr_dev), dst=own)
+            rep = torch.zeros(2, dtype=torch.int64, device=hdr_dev)
+            dist.recv(rep, src=own)
+            nx, nc = (int(x) for x in rep.tolist())
+            t = (nx - seg_start) // TILE
+            cand = torch.empty(nc * 16, dtype=torch.uint8, device=hdr_dev)
+            toff = torch.empty((t + 1) * 4, dtype=torch.uint8, device=hdr_dev)
+            bmp = torch.empty(t * (TILE // 8), dtype=torch.uint8, device=hdr_dev)
+            if nc:
+                dist.recv(cand, src=own)
+            dist.recv(toff, src=own)
+            if t:
+                dist.recv(bmp, src=own)
+            served["bytes"] += cand.numel() + toff.numel() + bmp.numel()
+            return cand, toff, bmp, nx, nc
 
-        ctx.set_tag_provider(provider)
+        ctx.set_cand_provider(provider)
         try:
             ctx.victim_round = victim_round
-            out = ctx.rzip_chunk(chunk)
+            out = ctx.rzip_chunk(window)
         finally:
-            ctx.set_tag_provider(None)
+            ctx.set_cand_provider(None)
             if own_scan_ctx is not None:
                 own_scan_ctx.close()
-            if world > 1:
-                dist.broadcast(torch.tensor([-1, 0, 0, 0, 0], dtype=torch.int64), src=0)
+            for r in range(1, world):
+                dist.send(torch.tensor([-1, 0, 0, 0, 0], dtype=torch.int64, device=hdr_dev), dst=r)
+        ctx.window_served = served
         return out
-    # ---- the other ranks: serve the segments of their range until rank 0 says it is done
-    if gather_bytes:
-        dist.gather_object(bytes(my_bytes[:ranges[rank][1]]), None, dst=0)
-    hdr = torch.zeros(5, dtype=torch.int64)
+    # ---- the other ranks: serve the stretches of their range until rank 0 says it is done
+    if window is None:
+        mine = bytes(my_bytes[:ranges[rank][1]].cpu().numpy().tobytes()) if hasattr(my_bytes, "data_ptr") else bytes(my_bytes[:ranges[rank][1]])
+        dist.gather_object(mine, None, dst=0)
+    hdr = torch.zeros(5, dtype=torch.int64, device=hdr_dev)
     while True:
-        dist.broadcast(hdr, src=0)
-        seg_index, seg_start, seg_len, min_mask, p_done = (int(x) for x in hdr)
-        if seg_index < 0:
+        dist.recv(hdr, src=0)
+        seg_start, span, min_mask, p_done, capx = (int(x) for x in hdr.tolist())
+        if seg_start < 0:
             return None
-        if owner_of(seg_start) != rank:
-            continue
-        tags, bitmap = scan(seg_start, seg_len, min_mask, p_done)
-        dist.send(torch.frombuffer(bytearray(tags), dtype=torch.int64), dst=0)
-        dist.send(torch.frombuffer(bytearray(bitmap), dtype=torch.int64), dst=0)
+        cand, toff, bmp, nx, nc = scan(seg_start, span, min_mask, p_done, capx)
+        t = (nx - seg_start) // TILE
+        dist.send(torch.tensor([nx, nc], dtype=torch.int64, device=hdr_dev), dst=0)
+        if device is None:
+            cand, toff, bmp = _tensor_of(cand, torch.uint8, None), _tensor_of(toff, torch.uint8, None), _tensor_of(bmp, torch.uint8, None)
+        if nc:
+            dist.send(cand[:nc * 16].contiguous(), dst=0)
+        dist.send(toff[:(t + 1) * 4].contiguous(), dst=0)
+        if t:
+            dist.send(bmp[:t * (TILE // 8)].contiguous(), dst=0)

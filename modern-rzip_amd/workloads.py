@@ -111,3 +111,60 @@ def stride_stream(nseg, seg_bytes, copy_bytes=None, seed=99):
         if i - k >= 0:
             segs[i][:copy_bytes] = segs[i - k][:copy_bytes]
     return b"".join(s.tobytes() for s in segs)
+
+
+def tar_like_device(nbytes, device, seed=5, pool_bytes=48 << 20, max_member_log2=22):
+    """The S3 mix of tar_like_fast built directly in HBM (BASELINE configs[2] at its full 64 GiB does not fit the host's
+    generators): text members are slices of one Zipf text pool at random offsets, noise members come from torch's
+    generator on the device, 15 % are exact duplicates of earlier members; 512-byte aligned.  Deterministic for a given
+    (nbytes, seed, torch version), NOT byte-identical to tar_like_fast (different noise generator): the oracle is run on
+    a prefix copied back from the device.  Returns a uint8 tensor of nbytes bytes."""
+    import torch
+    rng = np.random.default_rng(seed)
+    pool = torch.frombuffer(bytearray(zipf_text(pool_bytes, seed=seed + 1)), dtype=torch.uint8).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(nbytes + (8 << 20), dtype=torch.uint8, device=device)
+    at, members = 0, []
+    while at < nbytes:
+        kind = rng.random()
+        size = int(2 ** rng.uniform(10, max_member_log2))
+        if kind < 0.6 or not members:
+            off = int(rng.integers(0, pool_bytes - size))
+            out[at:at + size] = pool[off:off + size]
+        elif kind < 0.85:
+            out[at:at + size].random_(0, 256, generator=g)
+        else:
+            m0, msz = members[int(rng.integers(0, len(members)))]
+            size = msz
+            out[at:at + size] = out[m0:m0 + size].clone() if m0 + size > at else out[m0:m0 + size]
+        members.append((at, size))
+        at += size
+        pad = (-at) % 512
+        out[at:at + pad] = 0
+        at += pad
+    return out[:nbytes]
+
+
+def noise_device(nbytes, device, seed=99):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    for a in range(0, nbytes, 1 << 30):  # (slice-wise: random_ materialises temporaries of the slice's size)
+        out[a:a + (1 << 30)].random_(0, 256, generator=g)
+    return out
+
+
+def stride_stream_device(nseg, seg_bytes, device, copy_bytes=None, seed=99):
+    """stride_stream's shape built in HBM (BASELINE configs[3]: 1 GiB segments, every 4th repeats the first quarter of the
+    segment 1, 3 or 7 segments earlier)."""
+    copy_bytes = seg_bytes // 4 if copy_bytes is None else copy_bytes
+    out = noise_device(nseg * seg_bytes, device, seed=seed)
+    ks, j = (1, 3, 7), 0
+    for i in range(3, nseg, 4):
+        k = ks[j % 3]
+        j += 1
+        if i - k >= 0:
+            out[i * seg_bytes:i * seg_bytes + copy_bytes] = out[(i - k) * seg_bytes:(i - k) * seg_bytes + copy_bytes]
+    return out

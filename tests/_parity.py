@@ -4,12 +4,19 @@ import hashlib
 import modern_rzip_amd as m
 
 
-def check_chunk(lib, oracle, data, level=7, victim_round=0, table=False):
+def check_chunk(lib, oracle, data, level=7, victim_round=0, table=False, seg_positions=None, cand_cap=None, xcd=None):
     """mrz_rzip_chunk vs mrzo_rzip_chunk: both streams, CRC, the seven counters,
-    victim_round, final mask / hash_count (and optionally the whole table)."""
+    victim_round, final mask / hash_count (and optionally the whole table).  seg_positions / cand_cap shrink the
+    front end's passes (several segments per chunk; lists that fill up)."""
     want = oracle.rzip_chunk(data, level=level, victim_round=victim_round, want_table=table)
     with m.RzipContext(level=level, max_chunk=len(data), lib=lib) as ctx:
         ctx.victim_round = victim_round
+        if seg_positions:
+            ctx.set_segment_positions(seg_positions)
+        if cand_cap:
+            ctx.set_candidate_capacity(cand_cap)
+        if xcd is not None:
+            ctx.set_xcd(xcd)
         res, s0, s1 = ctx.rzip_chunk(data)
         assert res.crc32 == want["crc"]
         assert res.stats.as_dict() == want["stats"]

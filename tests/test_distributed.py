@@ -76,17 +76,20 @@ def _worker(rank, world, port, q):
             crc = shard.chunk_crc_sharded(big, rank, world, c2.crc32, dist)
         if rank == 0:
             assert crc == zlib.crc32(big)
-        # (4) ONE window over the two ranks (BASELINE configs[3], scaled): every rank scans the tags of the segments in
-        # its byte range, rank 0 runs the exact matcher over them; streams identical to the single-process oracle
+        # (4) ONE window over the two ranks (BASELINE configs[3], scaled): every rank runs the front end over the
+        # stretches in its byte range (compacted candidate records), rank 0 runs the exact matcher over them; streams
+        # identical to the single-process oracle
         from modern_rzip_amd import workloads
         win = workloads.stride_stream(8, 96 * 1024, seed=50)  # noise, every 4th segment repeats an earlier one
-        segp = 64 * 1024
-        ranges = shard.segment_ranges(len(win), world, segp)
+        ranges = shard.window_ranges(len(win), world)
         off, size = ranges[rank]
         mine = win[off:off + size + 48]  # own range + halo
         with m.RzipContext(lib=lib, max_chunk=len(win)) as c3:
-            out = shard.rzip_chunk_window(c3, mine, off, len(win), rank, world, dist, segp, victim_round=5)
+            c3.set_segment_positions(64 * 1024)  # several stretches per range
+            out = shard.rzip_chunk_window(c3, mine, off, len(win), rank, world, dist, victim_round=5, cap=20000)
             crc = shard.chunk_crc_sharded(win, rank, world, c3.crc32, dist)
+            if rank == 0:
+                assert c3.window_served["remote"] >= 2 and c3.window_served["n"] > c3.window_served["remote"]
         if rank == 0:
             res, s0, s1 = out
             want = oracle.rzip_chunk(win, victim_round=5)
@@ -141,24 +144,32 @@ def test_crc32_combine_and_ranges():
 
 
 def test_window_scan_of_ranges_equals_local_scan(emu_lib, oracle):
-    """The tag provider path on one process: segments scanned from byte ranges (with halo) give the same streams."""
+    """The candidate provider path on one process: stretches scanned from byte ranges (with halo) by another context
+    give the same streams; the matcher asks for one stretch after another, each from where the last pass ended."""
     import modern_rzip_amd as m
     from modern_rzip_amd import shard, workloads
     from tests import _util
     data = _util.zipf_text(150000, seed=9) + workloads.stride_stream(4, 40000, seed=3)
-    segp = 32 * 1024
     want = oracle.rzip_chunk(data)
     with m.RzipContext(lib=emu_lib, max_chunk=len(data)) as ctx, m.RzipContext(lib=emu_lib, max_chunk=len(data)) as other:
-        ranges = shard.segment_ranges(len(data), 3, segp)
-        assert sum(n for _, n in ranges) == len(data) and all(o % segp == 0 for o, _ in ranges)
+        ranges = shard.window_ranges(len(data), 3)
+        assert sum(n for _, n in ranges) == len(data) and all(o % 4096 == 0 for o, _ in ranges)
+        calls = []
 
-        def provider(seg_index, seg_start, seg_len, min_mask, p_done):
+        def provider(seg_start, span, min_mask, p_done, cap):
             r = max(i for i in range(3) if ranges[i][0] <= seg_start and ranges[i][1])
             off, size = ranges[r]
-            return other.window_scan(data[off:off + size + 48], off, len(data), seg_start, seg_len, min_mask, p_done)
+            end = off + size if r < 2 else -(-len(data) // 4096) * 4096
+            span = max(4096, min(span, end - seg_start))
+            out = other.window_scan(data[off:off + size + 48], off, len(data), seg_start, span, min_mask, p_done, cap=cap)
+            calls.append((seg_start, span, out[3], out[4]))
+            return out
 
-        ctx.set_segment_positions(segp)
-        ctx.set_tag_provider(provider)
+        ctx.set_segment_positions(32 * 1024)
+        ctx.set_candidate_capacity(6000)
+        ctx.set_cand_provider(provider)
         res, s0, s1 = ctx.rzip_chunk(data)
-        ctx.set_tag_provider(None)
+        ctx.set_cand_provider(None)
         assert (s0, s1) == (want["s0"], want["s1"]) and res.stats.as_dict() == want["stats"]
+        assert len(calls) > 10 and all(nc <= 6000 for _, _, _, nc in calls)
+        assert all(calls[i][2] == calls[i + 1][0] for i in range(len(calls) - 1))

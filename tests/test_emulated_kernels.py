@@ -85,6 +85,31 @@ def test_sequencer_workgroups_take_turns(emu_lib, oracle, wgs, monkeypatch):
     _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 19, seed=4), level=1, table=True)
 
 
+@pytest.mark.parametrize("engine", ["wide", "narrow"])
+def test_front_end_passes_and_full_lists(emu_lib, oracle, engine, monkeypatch):
+    """The candidate list of the front end: several passes per chunk (small spans), passes cut short because the list is
+    full (small capacity, down to one tile), a run of one byte whose tag passes the mask at EVERY position (all
+    positions are candidates), matches that jump over whole passes; each engine alone."""
+    monkeypatch.setenv("MRZ_SEQ_ENGINE", engine)
+    text = _util.zipf_text(70000, seed=4)
+    _parity.check_chunk(emu_lib, oracle, text, seg_positions=4096)
+    _parity.check_chunk(emu_lib, oracle, text, seg_positions=16384, cand_cap=4096, table=True)
+    noise = _util.xorshift_noise(50000, seed=3)
+    _parity.check_chunk(emu_lib, oracle, noise, seg_positions=8192, cand_cap=5000)
+    blk = _util.xorshift_noise(30000, seed=12)
+    _parity.check_chunk(emu_lib, oracle, blk + blk + text[:9000] + blk, seg_positions=4096, victim_round=2)
+    # runs of one byte: the tag of a run is hash_index[b] (31 equal terms); for half the byte values it passes the 1-bit
+    # mask, and then EVERY position of the run is in the list (each pass is cut after one tile); the matcher swallows
+    # the run as one match
+    swallowed = 0
+    for b in (0, 1, 2, 3):
+        run = bytes([b]) * 21000 + text[:3000] + bytes([b]) * 6000
+        # (capacity 8192 -> passes of 3 tiles under the 1-bit mask: two tiles of a run fill the list, the third is cut off)
+        swallowed += _parity.check_chunk(emu_lib, oracle, run, seg_positions=16384, cand_cap=8192)["stats"]["matches"] >= 2
+    assert swallowed >= 1
+    _parity.check_chunk(emu_lib, oracle, _util.rep64k(5, seed=5, period=8192), level=4, seg_positions=8192, xcd=5)
+
+
 def test_crc32_kernel(emu_lib):
     with m.RzipContext(lib=emu_lib) as ctx:
         for n in (0, 1, 15, 16, 17, 1000, 65535, 65536, 65537, 3 * 65536 + 77):

@@ -29,7 +29,7 @@ def inputs():
 def test_native_library_is_loaded(gpu_lib):
     import torch
     assert torch.cuda.is_available()
-    assert gpu_lib.mrz_abi_version() == 2
+    assert gpu_lib.mrz_abi_version() == 3
     assert os.path.basename(m.lib_path()) == "libmrzgpu.so"
     with open("/proc/self/maps") as f:
         assert "libmrzgpu.so" in f.read()
