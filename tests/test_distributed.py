@@ -145,7 +145,8 @@ def test_crc32_combine_and_ranges():
 
 def test_window_scan_of_ranges_equals_local_scan(emu_lib, oracle):
     """The candidate provider path on one process: stretches scanned from byte ranges (with halo) by another context
-    give the same streams; the matcher asks for one stretch after another, each from where the last pass ended."""
+    give the same streams; the matcher asks for one stretch after another, each from where the last pass ended (or
+    further on, at the tile of the matcher's position, when an emitted match has swallowed what lies between)."""
     import modern_rzip_amd as m
     from modern_rzip_amd import shard, workloads
     from tests import _util
@@ -172,4 +173,5 @@ def test_window_scan_of_ranges_equals_local_scan(emu_lib, oracle):
         ctx.set_cand_provider(None)
         assert (s0, s1) == (want["s0"], want["s1"]) and res.stats.as_dict() == want["stats"]
         assert len(calls) > 10 and all(nc <= 6000 for _, _, _, nc in calls)
-        assert all(calls[i][2] == calls[i + 1][0] for i in range(len(calls) - 1))
+        assert all(calls[i][2] <= calls[i + 1][0] for i in range(len(calls) - 1))
+        assert sum(calls[i][2] == calls[i + 1][0] for i in range(len(calls) - 1)) > len(calls) // 2
