@@ -287,34 +287,34 @@ def main():
 
 
 def window_mode(args, m, workloads, lib, dist, rank, world, dev_index):
-    """ONE window over the ranks (BASELINE configs[3], scaled to --gib): S4 stride stream; every rank runs the front end
-    over the stretches of its byte range and ships compacted candidate records to rank 0 (send/recv: RCCL moves device
-    tensors GPU to GPU; gloo takes the host path), the exact matcher runs on rank 0."""
+    """ONE window over the ranks (BASELINE configs[3], scaled to --gib): S4 stride stream.  Every rank keeps its byte range
+    in a shareable allocation in its own HBM and maps all ranges into one address range (shard.window_map: HIP virtual
+    memory management, peer loads over xGMI); every rank runs the front end over the stretches of its range and ships
+    compacted candidate records to rank 0 (send/recv: RCCL moves device tensors GPU to GPU; gloo takes the host path);
+    the exact matcher runs on rank 0 and reads the other ranks' bytes through the mapping."""
     import torch
     from modern_rzip_amd import shard
-    seg_bytes = max(int(args.gib * GIB) // 16 // 4096, 1) * 4096
-    total = 16 * seg_bytes
     dev = torch.device("cuda", dev_index)
     use_dev = args.dist_backend == "nccl"
-    ranges = shard.window_ranges(total, world)
-    off, size = ranges[rank]
-    # the same bytes on every rank (seeded generator on the device); a rank keeps its range (+ halo), rank 0 the window
-    win = workloads.stride_stream_device(16, seg_bytes, dev, seed=99)
-    mine = win[off:off + size + 48].clone()
-    window = win if rank == 0 else None
-    if rank != 0:
-        del win
-        torch.cuda.empty_cache()
+    g = m.window_granularity(dev_index, lib)
+    seg_bytes = max(int(args.gib * GIB) // 16 // g, 1) * g
+    total = 16 * seg_bytes
     ctx = m.RzipContext(level=args.level, max_chunk=total if rank == 0 else 0, device=dev_index, lib=lib)
+    # the same bytes on every rank (seeded generator on the device); a rank keeps its range only
+    win = workloads.stride_stream_device(16, seg_bytes, dev, seed=99)
+    wmap, part, ranges = shard.window_map(lambda o, n: win[o:o + n], total, rank, world, dist, ctx, device=dev_index)
+    del win
+    torch.cuda.empty_cache()
+    off, size = ranges[rank]
+    mine = (wmap.ptr + off, min(size + 48, total - off))
     times = []
     res = None
     for it in range(args.warmup + args.steps):
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = shard.rzip_chunk_window(ctx, mine if use_dev else bytes(mine.cpu().numpy().tobytes()), off, total, rank, world,
-                                      dist, window=window if rank == 0 else b"", device=dev if use_dev else None,
-                                      cap=8 << 20, ranges=ranges)
+        out = shard.rzip_chunk_window(ctx, mine, off, total, rank, world, dist, window=(wmap.ptr, total),
+                                      device=dev if use_dev else None, cap=8 << 20, ranges=ranges)
         torch.cuda.synchronize()
         dist.barrier()
         if it >= args.warmup:
@@ -328,11 +328,16 @@ def window_mode(args, m, workloads, lib, dist, rank, world, dev_index):
                           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                           "config": {"workload": f"stride-{total / GIB:g}G: ONE window (-U) of noise segments with planted "
-                                                 f"repeats (BASELINE configs[3], scaled), front end range-sharded over the "
-                                                 f"ranks, candidate records to rank 0 over {args.dist_backend}",
+                                                 f"repeats (BASELINE configs[3], scaled), byte ranges in the ranks' own HBM "
+                                                 f"mapped into one address range, front end range-sharded, candidate "
+                                                 f"records to rank 0 over {args.dist_backend}",
                                      "mode": "window", "level": args.level, "window_bytes": total,
                                      "served": getattr(ctx, "window_served", None)},
-                          "result": {"s0_len": res.s0_len, "s1_len": res.s1_len, "matches": res.stats.matches}}), flush=True)
+                          "result": {"s0_len": res.s0_len, "s1_len": res.s1_len, "matches": res.stats.matches,
+                                     "crc32": f"{res.crc32:08x}"}}), flush=True)
+    dist.barrier()
+    wmap.close()
+    part.close()
     ctx.close()
     dist.destroy_process_group()
 

@@ -170,6 +170,27 @@ int mrz_set_candidate_capacity(mrz_ctx *ctx, int64_t entries);
  * buffers with); returns when the source may be reused */
 int mrz_copy_to_device(mrz_ctx *ctx, void *dst_device, const void *src_host, int64_t n);
 int mrz_copy_device(mrz_ctx *ctx, void *dst_device, const void *src_device, int64_t n);
+/* The window's BYTES when its ranges live on several GPUs (one process per GPU).  The reference maps the whole file and
+ * single_match_len compares anywhere in it (src/rzip.c:372-397; -U: one chunk = the file, :881-882).  Here every rank
+ * keeps its range in its own HBM as a shareable physical allocation (HIP virtual memory management):
+ *   mrz_window_part_create   allocates `bytes` (a multiple of mrz_window_granularity) on `device`, maps it for the
+ *                            owner (*dptr: where the owner writes its range) and exports it as a POSIX file descriptor
+ *                            (*fd, owned by the part) that the host program hands to the other processes (SCM_RIGHTS);
+ *   mrz_window_map_create    imports n_parts descriptors (its own among them) and maps them back to back, in the order
+ *                            given, into ONE virtual address range on `device`: *dptr + position is the window's byte,
+ *                            whichever GPU holds it -- loads that fall into another rank's range go over xGMI.  The
+ *                            matcher's rank passes it to mrz_rzip_chunk as the chunk (MRZ_MEM_DEVICE): match extension,
+ *                            compare farm, literal gather and CRC read the bytes where they lie, nothing is gathered;
+ *                            the other ranks pass their range of it (plus the 48-byte halo, which is the next rank's
+ *                            memory) to mrz_window_scan.
+ * Sizes are the mapped sizes of the parts (multiples of the granularity); the descriptors stay the caller's. */
+typedef struct mrz_window_part mrz_window_part;
+typedef struct mrz_window_map mrz_window_map;
+int64_t mrz_window_granularity(int device); /* > 0, or a negative MRZ_E_ code */
+int mrz_window_part_create(int device, int64_t bytes, mrz_window_part **out, void **dptr, int *fd);
+void mrz_window_part_destroy(mrz_window_part *part);
+int mrz_window_map_create(int device, int n_parts, const int *fds, const int64_t *sizes, mrz_window_map **out, void **dptr);
+void mrz_window_map_destroy(mrz_window_map *map);
 /* Which of the GPU's 8 XCDs carries this ctx's sequencer workgroups (0..7; default 0): block index mod 8 under the
  * round-robin placement of workgroups.  The exact matcher of one chunk is one dependency chain on one XCD; ctxs that run
  * concurrently (independent streams, chunks of one file) should get different values so that each has an XCD's

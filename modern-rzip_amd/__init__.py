@@ -16,6 +16,9 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from .binding import (  # noqa: E402,F401
     MrzError,
     RzipContext,
+    WindowPart,
+    WindowMap,
+    window_granularity,
     ChunkResult,
     Stats,
     Timings,
@@ -33,6 +36,6 @@ from .binding import (  # noqa: E402,F401
 )
 
 __all__ = [
-    "MrzError", "RzipContext", "ChunkResult", "Stats", "Timings", "Control", "lib_path", "load_library",
+    "MrzError", "RzipContext", "WindowPart", "WindowMap", "window_granularity", "ChunkResult", "Stats", "Timings", "Control", "lib_path", "load_library",
     "chunk_bytes", "rzip_buffer", "rzip_stream_buffer", "rzip_fd", "runzip_buffer", "rzip_pipeline", "MEM_HOST", "MEM_DEVICE",
 ]

@@ -107,6 +107,16 @@ def load_library(path=None):
         lib.mrz_set_xcd.argtypes = [vp, ci]
         lib.mrz_copy_to_device.argtypes = [vp, vp, vp, i64]
         lib.mrz_copy_device.argtypes = [vp, vp, vp, i64]
+    if hasattr(lib, "mrz_window_map_create"):
+        lib.mrz_window_granularity.argtypes = [ci]
+        lib.mrz_window_granularity.restype = i64
+        lib.mrz_window_part_create.argtypes = [ci, i64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ci)]
+        lib.mrz_window_part_destroy.argtypes = [vp]
+        lib.mrz_window_part_destroy.restype = None
+        lib.mrz_window_map_create.argtypes = [ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(vp),
+                                              ctypes.POINTER(vp)]
+        lib.mrz_window_map_destroy.argtypes = [vp]
+        lib.mrz_window_map_destroy.restype = None
     lib.mrz_stream.argtypes = [vp]
     lib.mrz_stream.restype = vp
     lib.mrz_synchronize.argtypes = [vp]
@@ -187,6 +197,49 @@ def _as_ptr(buf):
     return ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p), len(b), MEM_HOST, b
 
 
+class WindowPart:
+    """mrz_window_part: this rank's byte range of a window as a shareable allocation (ptr: where the owner writes it,
+    fd: the descriptor the other ranks import; both live as long as the part)."""
+
+    def __init__(self, nbytes, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.handle, ptr, fd = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(-1)
+        _check(self.lib, self.lib.mrz_window_part_create(device, nbytes, ctypes.byref(self.handle), ctypes.byref(ptr),
+                                                         ctypes.byref(fd)))
+        self.ptr, self.fd, self.nbytes = ptr.value, fd.value, nbytes
+
+    def close(self):
+        if self.handle:
+            self.lib.mrz_window_part_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+class WindowMap:
+    """mrz_window_map: the parts of all ranks (descriptors in range order) mapped back to back; ptr + position is the
+    window's byte."""
+
+    def __init__(self, fds, sizes, device=0, lib=None):
+        self.lib = lib or load_library()
+        n = len(fds)
+        self.handle, ptr = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(self.lib, self.lib.mrz_window_map_create(device, n, (ctypes.c_int * n)(*fds), (ctypes.c_int64 * n)(*sizes),
+                                                        ctypes.byref(self.handle), ctypes.byref(ptr)))
+        self.ptr, self.nbytes = ptr.value, sum(sizes)
+
+    def close(self):
+        if self.handle:
+            self.lib.mrz_window_map_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+def window_granularity(device=0, lib=None):
+    lib = lib or load_library()
+    g = lib.mrz_window_granularity(device)
+    if g <= 0:
+        _check(lib, int(g))
+    return int(g)
+
+
 class RzipContext:
     """One mrz_ctx: the per-file half of rzip_fd (src/rzip.c:836-913)."""
 
@@ -230,6 +283,12 @@ class RzipContext:
 
     def set_xcd(self, xcd):
         _check(self.lib, self.lib.mrz_set_xcd(self.ctx, xcd), self.ctx)
+
+    def copy_to(self, dst_ptr, src):
+        """Copies bytes / a (cuda or cpu) uint8 tensor to device address dst_ptr on the ctx stream."""
+        ptr, n, where, keep = _as_ptr(src)
+        fn = self.lib.mrz_copy_device if where == MEM_DEVICE else self.lib.mrz_copy_to_device
+        _check(self.lib, fn(self.ctx, ctypes.c_void_p(dst_ptr), ptr, n), self.ctx)
 
     def window_scan(self, range_bytes, range_start, chunk_n, seg_start, max_span, min_mask, p_done=0, cap=1 << 20,
                     out=None):

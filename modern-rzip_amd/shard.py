@@ -223,6 +223,82 @@ def window_ranges(total, world, align=TILE):
     return out
 
 
+def exchange_fds(my_fd, rank, world, dist):
+    """Every rank contributes one file descriptor (its window part, mrz_window_part_create) and gets back the list of
+    all ranks' descriptors, valid in ITS process.  Descriptors cannot travel through torch.distributed: rank 0 listens on
+    a Unix socket (its path goes round by broadcast_object_list), the others connect and pass theirs as SCM_RIGHTS
+    ancillary data, rank 0 answers each with the full set."""
+    import os
+    import socket
+    import tempfile
+    if world == 1:
+        return [my_fd]
+    path = [None]
+    srv = None
+    if rank == 0:
+        path[0] = os.path.join(tempfile.mkdtemp(prefix="mrzwin"), "fds.sock")
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(path[0])
+        srv.listen(world)
+    dist.broadcast_object_list(path, src=0)
+    if rank == 0:
+        conns, fds = {}, {0: my_fd}
+        try:
+            for _ in range(world - 1):
+                c, _ = srv.accept()
+                msg, got, _, _ = socket.recv_fds(c, 16, 1)
+                r = int(msg.decode())
+                conns[r], fds[r] = c, got[0]
+            order = [fds[r] for r in range(world)]
+            for r, c in conns.items():
+                socket.send_fds(c, [b"ok"], order)
+                c.recv(2)  # the peer has its copies
+        finally:
+            for c in conns.values():
+                c.close()
+            srv.close()
+            os.unlink(path[0])
+            os.rmdir(os.path.dirname(path[0]))
+        return order
+    c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    c.connect(path[0])
+    try:
+        socket.send_fds(c, [str(rank).encode()], [my_fd])
+        _, got, _, _ = socket.recv_fds(c, 16, world)
+        c.send(b"ok")
+    finally:
+        c.close()
+    return list(got)
+
+
+def window_map(data_of_range, total, rank, world, dist, ctx, device=0):
+    """The window's bytes over the ranks (mrz_window_part_create / mrz_window_map_create, include/mrzgpu.h): every rank
+    puts its range -- data_of_range(off, size) -> bytes or a uint8 tensor -- into a shareable allocation in its own HBM,
+    the descriptors go round (exchange_fds), and every rank maps all parts back to back: map.ptr + position is the
+    window's byte whichever GPU holds it.  Ranges are whole allocation granules (window_ranges(total, world, granule)).
+    Returns (WindowMap, WindowPart, ranges); close both when done (the map first)."""
+    import os
+    from .binding import WindowMap, WindowPart, window_granularity
+    g = window_granularity(device, ctx.lib)
+    ranges = window_ranges(total, world, align=g)
+    if any(n == 0 for _, n in ranges):
+        raise ValueError("a window of %d bytes does not give each of %d ranks a whole %d-byte granule" % (total, world, g))
+    off, size = ranges[rank]
+    mapped = -(-size // g) * g  # (the last range is padded to a whole granule)
+    part = WindowPart(mapped, device=device, lib=ctx.lib)
+    ctx.copy_to(part.ptr, data_of_range(off, size))
+    sizes = [-(-n // g) * g for _, n in ranges]
+    fds = exchange_fds(part.fd, rank, world, dist)
+    try:
+        wmap = WindowMap(fds, sizes, device=device, lib=ctx.lib)
+    finally:
+        for r, fd in enumerate(fds):
+            if r != rank:
+                os.close(fd)  # (imported: the map holds the allocations now)
+    dist.barrier()
+    return wmap, part, ranges
+
+
 def _tensor_of(buf, dtype, device):
     import torch
     t = torch.frombuffer(bytearray(buf), dtype=dtype) if len(buf) else torch.empty(0, dtype=dtype)

@@ -126,3 +126,59 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess (emulator)" : "emulated HIP error"; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 #define hipStreamNonBlocking 1
+
+// ---- virtual memory management subset (mrz_window.hip): physical allocation = memfd, mapping = mmap -------------
+// What HIP's VMM gives on the GPU (shareable physical allocations mapped back to back into one reserved address range,
+// across processes) is what memfd + MAP_FIXED give on the CPU: the multi-process window tests run on it unchanged.
+#include <sys/mman.h>
+#include <unistd.h>
+typedef struct { int fd; size_t size; } *hipMemGenericAllocationHandle_t;
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAllocationHandleType { hipMemHandleTypePosixFileDescriptor = 1 };
+enum hipMemAllocationGranularity_flags { hipMemAllocationGranularityRecommended = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation { hipMemLocationType type; int id; };
+struct hipMemAllocationProp { hipMemAllocationType type; hipMemAllocationHandleType requestedHandleType; hipMemLocation location; };
+struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
+static inline hipError_t hipMemGetAllocationGranularity(size_t *g, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { *g = 65536; return hipSuccess; }
+static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t size, const hipMemAllocationProp *, unsigned long long) {
+    const int fd = memfd_create("mrz_emu_window", 0);
+    if (fd < 0 || ftruncate(fd, (off_t)size) != 0) { if (fd >= 0) close(fd); return hipErrorOutOfMemory; }
+    *h = (hipMemGenericAllocationHandle_t)malloc(sizeof(**h));
+    (*h)->fd = fd;
+    (*h)->size = size;
+    return hipSuccess;
+}
+static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { if (h) { close(h->fd); free(h); } return hipSuccess; }
+static inline hipError_t hipMemExportToShareableHandle(void *out, hipMemGenericAllocationHandle_t h, hipMemAllocationHandleType, unsigned long long) {
+    const int d = dup(h->fd);
+    if (d < 0) return hipErrorInvalidValue;
+    *(int *)out = d;
+    return hipSuccess;
+}
+static inline hipError_t hipMemImportFromShareableHandle(hipMemGenericAllocationHandle_t *h, void *os_handle, hipMemAllocationHandleType) {
+    const int d = dup(*(int *)os_handle);
+    if (d < 0) return hipErrorInvalidValue;
+    const off_t size = lseek(d, 0, SEEK_END);
+    if (size <= 0) { close(d); return hipErrorInvalidValue; }
+    *h = (hipMemGenericAllocationHandle_t)malloc(sizeof(**h));
+    (*h)->fd = d;
+    (*h)->size = (size_t)size;
+    return hipSuccess;
+}
+static inline hipError_t hipMemAddressReserve(void **p, size_t size, size_t, void *, unsigned long long) {
+    void *a = mmap(nullptr, size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (a == MAP_FAILED) return hipErrorOutOfMemory;
+    *p = a;
+    return hipSuccess;
+}
+static inline hipError_t hipMemAddressFree(void *p, size_t size) { munmap(p, size); return hipSuccess; }
+static inline hipError_t hipMemMap(void *p, size_t size, size_t, hipMemGenericAllocationHandle_t h, unsigned long long) {
+    if (size > h->size) return hipErrorInvalidValue;
+    return mmap(p, size, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, h->fd, 0) == MAP_FAILED ? hipErrorInvalidValue : hipSuccess;
+}
+static inline hipError_t hipMemUnmap(void *p, size_t size) {
+    return mmap(p, size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == MAP_FAILED ? hipErrorInvalidValue : hipSuccess;
+}
+static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipSuccess; }

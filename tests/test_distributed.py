@@ -118,6 +118,34 @@ def test_two_ranks_over_gloo(emu_lib, oracle):
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
 
 
+def run_window_workers(which, segments, seg_bytes, timeout=600, backend="gloo"):
+    """Two FRESH processes (started before anything in them touches a device), one rank each, over the window-sharded
+    path with peer-mapped window memory: tests/_window_worker.py.  Returns rank 0's output."""
+    import subprocess
+    port = 29500 + (os.getpid() * 7 + 13) % 2000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_window_worker.py"), str(r), "2", str(port), which,
+                               str(segments), str(seg_bytes), backend], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs) and "window ok" in outs[0], "\n----\n".join(o[-3000:] for o in outs)
+    return outs[0]
+
+
+def test_window_over_two_processes_with_mapped_ranges(emu_lib, oracle):
+    """BASELINE configs[3], scaled, on the emulator: every rank's byte range in a shareable allocation of its own, all
+    parts mapped back to back in both processes (the emulator's VMM subset is memfd + mmap), candidates shipped to rank 0,
+    whose matcher reads the other rank's bytes through the mapping; equal to the oracle."""
+    run_window_workers("emu", 8, 128 * 1024)
+
+
 def test_chunk_splitting_rules():
     from modern_rzip_amd import shard
     assert shard.split_chunks(0, 4096) == [(0, 0)]

@@ -473,6 +473,18 @@ def test_rzip_fd_on_a_pipe_and_on_a_file(gpu_lib, oracle, tmp_path):
     _parity.check_fd(gpu_lib, oracle, data, use_pipe=False, ramsize=3 << 20, tmp_path=tmp_path)
 
 
+def test_window_sharded_over_two_processes(gpu_lib):
+    """BASELINE configs[3] in its defining form, scaled to one box: ONE 256 MiB window (noise segments with planted
+    repeats at 1-, 3- and 7-segment strides) whose halves live in shareable allocations of two fresh processes (both on
+    GPU 0, gloo transport); both map both halves into one address range (mrz_window_map_create), each scans the
+    stretches of its half (mrz_window_scan from the mapping, halo included) and ships compacted candidates to rank 0,
+    whose matcher, compare farm, CRC and literal gather read rank 1's bytes through the mapping.  Rank 0 compares both
+    streams, the counters, the CRC and victim_round with the oracle."""
+    from tests.test_distributed import run_window_workers
+    out = run_window_workers("gpu", 16, 16 << 20, timeout=900)
+    assert "window ok 268435456" in out
+
+
 def test_c_caller_program(gpu_lib, tmp_path):
     """tests/c/capi_test.c: a plain C99 program (gcc, no ctypes) linked against libmrzgpu.so drives the chunk call and
     mrz_rzip_fd (file and pipe) and compares every byte with the oracle itself."""
