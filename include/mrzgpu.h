@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRZ_ABI_VERSION 3
+#define MRZ_ABI_VERSION 4
 
 enum {
     MRZ_OK = 0,
@@ -80,6 +80,8 @@ typedef struct {
     float total_ms;     /* first launch -> last kernel done */
     int32_t n_segments; /* sequencer launches (segments an emitted match has covered are not launched) */
     int32_t n_narrow;   /* ... of which ran on the narrow engine (mrz_seq_narrow.hip) */
+    int32_t n_deep;     /* ... and on the deep engine (mrz_seq_deep.hip); the rest on the wide engine */
+    int32_t reserved;
 } mrz_timings;
 
 /* ---- context ----------------------------------------------------------- */

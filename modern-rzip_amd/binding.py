@@ -31,7 +31,7 @@ class ChunkResult(ctypes.Structure):
 class Timings(ctypes.Structure):
     _fields_ = [("tagscan_ms", ctypes.c_float), ("sequencer_ms", ctypes.c_float), ("encode_ms", ctypes.c_float),
                 ("crc_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("n_segments", ctypes.c_int32),
-                ("n_narrow", ctypes.c_int32)]
+                ("n_narrow", ctypes.c_int32), ("n_deep", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 # mrz_cand_provider_fn (include/mrzgpu.h)

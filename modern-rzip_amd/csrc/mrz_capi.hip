@@ -135,6 +135,9 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         const char *e = getenv("MRZ_SEQ_ENGINE");
         if (e && !strcmp(e, "wide")) ctx->engine_pin = 1;
         if (e && !strcmp(e, "narrow")) ctx->engine_pin = 2;
+        if (e && !strcmp(e, "deep")) ctx->engine_pin = 3;
+        ctx->deep_min_bits = 7;
+        if (const char *d = getenv("MRZ_DEEP_MIN_BITS")) ctx->deep_min_bits = atoi(d);
         e = getenv("MRZ_PRINT_PROF");
         if (e) ctx->print_prof = !strcmp(e, "narrow") ? 2 : 1;
     }
@@ -545,7 +548,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         STEP(hipEventCreateWithFlags(&seg_ev[k], hipEventDisableTiming));
         if (herr == hipSuccess) n_seg_ev++;
     }
-    int64_t launched = 0, retired = 0, n_narrow = 0;
+    int64_t launched = 0, retired = 0, n_narrow = 0, n_deep = 0;
     int64_t span_of[MRZ_SEG_AHEAD];      // positions the pass of an in-flight launch may cover
     int64_t known_next = 0;              // where the pass after the last retired launch begins, as far as the host knows
     int64_t known_mask = hs.min_mask, known_p = 0;
@@ -638,18 +641,26 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         // two launches are waited for so that it arrives early.  MRZ_SEQ_ENGINE=wide|narrow pins the choice (tests,
         // measurements).
         bool narrow = hint_pos > 0 && hint_matched * 10 >= hint_pos * 8;
-        if (ctx->engine_pin) narrow = ctx->engine_pin == 2;
+        // ... and the deep engine once the cull sweeps have tightened the mask: the table then consists of a few long
+        // runs (2^(hash_bits - k) of about 2/3 x 2^k slots under a k-bit mask) that every look-up reads to the end --
+        // streaming scans, not the short walks the wide engine's lanes are made for
+        bool deep = !narrow && __builtin_popcountll((unsigned long long)known_mask) >= ctx->deep_min_bits;
+        if (ctx->engine_pin) narrow = ctx->engine_pin == 2, deep = ctx->engine_pin == 3;
         const int helpers = ctx->farm_helpers >= 0 && ctx->farm_helpers < ctx->farm_default ? ctx->farm_helpers : ctx->farm_default;
         PROF_BEGIN(1);
         if (narrow)
             STEP(mrz_launch_sequencer_narrow(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
                                              ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->xcd));
+        else if (deep)
+            STEP(mrz_launch_sequencer_deep(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
+                                           ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->xcd));
         else
             STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
                                       ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->d_seq_shared, ctx->d_wlog,
-                                      ctx->nslots, ctx->seq_wgs, ctx->xcd));
+                                      ctx->nslots, ctx->seq_wgs, ctx->xcd, ctx->engine_pin ? 0 : ctx->deep_min_bits));
         PROF_END();
         if (narrow) n_narrow++;
+        if (deep) n_deep++;
         STEP(hipMemcpyAsync(&ctx->h_ring[launched % MRZ_SEG_AHEAD], ctx->d_state, snap_bytes, hipMemcpyDeviceToHost, s));
         STEP(hipEventRecord(seg_ev[launched % MRZ_SEG_AHEAD], s));
         launched++;
@@ -705,6 +716,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
 
     ctx->timings.n_segments = (int32_t)launched;
     ctx->timings.n_narrow = (int32_t)n_narrow;
+    ctx->timings.n_deep = (int32_t)n_deep;
     if (ctx->profiling) {
         hipStreamSynchronize(s);
         for (int i = 0; i < nev; i++) {
@@ -764,7 +776,9 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                           "t_turn", "t_prep", "t_precommit", "e_mask", "e_cull", "e_xw", "e_inwin", "e_window", "e_bulk",
                                           "e_more", "t_pc_cw", "t_pc_log", "t_pc_best", "t_pc_bulk", "t_turnwork", "t_snap", "rebulk",
                                           "batch_lanes", "cut_long", "cut_walk", "cut_conflict", "cut_cull", "batch_emits",
-                                          "cut_cascade", "batch_formed", "t_walk2", "t_scans", "t_conflict", "t_window" };
+                                          "cut_cascade", "batch_formed", "t_walk2", "t_scans", "t_conflict", "t_window",
+                                          "d_batches", "d_lanes", "d_rounds", "d_rescanned", "d_coop", "d_t_form", "d_t_scan",
+                                          "d_t_commit", "d_t_rescan", "d_t_total", "d_launches" };
         for (int k = 0; k < 128; k++)
             if (names[k] && hs.prof[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }

@@ -26,12 +26,15 @@ hipError_t mrz_launch_frontend(hipStream_t stream, const uint8_t *buf, int64_t n
 hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
                                 const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
                                 void *gmailbox, int n_helpers, void *wide_shared, unsigned *wlog,
-                                int64_t nslots, int seq_wgs, int xcd);
+                                int64_t nslots, int seq_wgs, int xcd, int deep_bits);
 size_t mrz_sequencer_shared_size(void);
 size_t mrz_sequencer_wlog_size(int64_t nslots);
 hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
                                        const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
                                        void *gmailbox, int n_helpers, int xcd);
+hipError_t mrz_launch_sequencer_deep(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
+                                     const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
+                                     void *gmailbox, int n_helpers, int xcd);
 size_t mrz_sequencer_mailbox_size(void);
 size_t mrz_seq_narrow_mailbox_size(void);
 int mrz_sequencer_default_helpers(int device);

@@ -84,6 +84,9 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        // (the narrow engine's own)
        MRZ_ST_BATCH_LANES, MRZ_ST_CUT_LONG, MRZ_ST_CUT_WALK, MRZ_ST_CUT_CONFLICT, MRZ_ST_CUT_CULL, MRZ_ST_BATCH_EMITS,
        MRZ_ST_CUT_CASCADE, MRZ_ST_BATCH_FORMED, MRZ_ST_T_WALK2, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_WINDOW,
+       // (the deep engine's own)
+       MRZ_ST_D_BATCHES, MRZ_ST_D_LANES, MRZ_ST_D_ROUNDS, MRZ_ST_D_RESCANNED, MRZ_ST_D_COOP, MRZ_ST_D_T_FORM, MRZ_ST_D_T_SCAN,
+       MRZ_ST_D_T_COMMIT, MRZ_ST_D_T_RESCAN, MRZ_ST_D_T_TOTAL, MRZ_ST_D_LAUNCHES,
        MRZ_ST_N };
 static_assert(MRZ_ST_N <= (int)(sizeof(((mrz_seq_state *)0)->prof) / sizeof(int64_t)), "mrz_seq_state.prof holds the counters");
 
@@ -98,6 +101,8 @@ struct mrz_seq_args {
     void *gmailbox;           // mrz_gmailbox in device memory, zeroed by the host before every launch
     int n_helpers;            // helper workgroups in this launch
     int xcd;                  // block index mod 8 of the sequencer workgroups
+    int deep_bits;            // wide engine: a launch ends where minimum_tag_mask reaches this many bits (the deep engine's
+                              // regime: the host relaunches the rest of the segment there); 0 = never
 };
 
 // the candidate list of one segment, as the sequencers see it

@@ -1029,6 +1029,7 @@ extern "C" hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint
     a.st = st;
     a.gmailbox = gmailbox;
     a.xcd = xcd & 7;
+    a.deep_bits = 0;
 #if MRZ_HELPER_WGS == 0
     n_helpers = 0;
 #endif

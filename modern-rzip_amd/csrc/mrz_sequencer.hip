@@ -120,6 +120,15 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
 #endif
 
     if (st->finished || st->error) return;
+    // the mask has reached the deep engine's regime (a launch queued before the host knew): nothing is sequenced here,
+    // the front end scans this stretch again (under the tighter mask) for the deep engine's launch
+    if (a.deep_bits > 0 && __popcll((unsigned long long)st->min_mask) >= a.deep_bits) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t pt = ((st->p + 1) >> MRZ_TILE_SHIFT) << MRZ_TILE_SHIFT;
+            if (st->seg_end > st->seg_start && pt < st->scan_next) st->scan_next = pt > st->seg_start ? pt : st->seg_start;
+        }
+        return;
+    }
     // which role: blocks 0, 8, 16, ... are sequencer workgroups (one XCD), the others compare-farm helpers
     int wgs = want_wgs < 1 ? 1 : (want_wgs > MRZ_SEQ_WGS ? MRZ_SEQ_WGS : want_wgs);
     const int bx = (int)blockIdx.x;
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
             __builtin_amdgcn_s_sleep(4);
         S->ctl[0] = (int)n;
         S->ctl[1] = n ? G->active[j] : -1;
+        S->ctl[8] = 0;
     }
     __syncthreads();
     n_act = mrz_uni(S->ctl[0]);
@@ -448,6 +458,14 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                                 finish = true;
                                 if (verdict2 == 1) verdict2 = 0;
                             }
+                            // the mask has reached the deep engine's regime: the launch ends here, the host relaunches
+                            // the rest of the stretch on that engine (the front end scans it again from the matcher's
+                            // position: scan_next is taken back below)
+                            if (masks_moved && a.deep_bits > 0 && __popcll((unsigned long long)L.min_mask) >= a.deep_bits && !finish) {
+                                finish = true;
+                                if (verdict2 == 1) verdict2 = 0;
+                                if (lane == 0) S->ctl[8] = 1;
+                            }
                             ST_ADD(MRZ_ST_E_MORE, (all_lanes && !window_done) ? 1 : 0);
                             ST_ADD(MRZ_ST_RESET, verdict2 == 2 ? 1 : 0);
                             ST_ADD(MRZ_ST_REPREP, verdict2 == 1 ? 1 : 0);
@@ -552,6 +570,10 @@ __global__ __launch_bounds__(MRZ_SEQ_THREADS) void mrz_sequencer_kernel(mrz_seq_
                 st->hint_positions = L.p - hint_p0;
                 st->hint_events = L.n_events - hint_ev0;
                 st->hint_matched = L.mbytes;
+                if (S->ctl[8] && L.p < lim) {  // ended early for the deep engine: the rest of the stretch is scanned again
+                    const int64_t pt = ((L.p + 1) >> MRZ_TILE_SHIFT) << MRZ_TILE_SHIFT;
+                    if (pt < st->scan_next) st->scan_next = pt > seg_start ? pt : seg_start;
+                }
                 MRZ_RELEASE_AGENT();
                 __hip_atomic_store(&G->quit, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #if MRZ_HELPER_WGS > 0
@@ -574,7 +596,7 @@ extern "C" size_t mrz_sequencer_wlog_size(int64_t nslots);
 extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
                                            const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
                                            void *gmailbox, int n_helpers, void *wide_shared, unsigned *wlog, int64_t nslots,
-                                           int seq_wgs, int xcd) {
+                                           int seq_wgs, int xcd, int deep_bits) {
     mrz_seq_args a;
     a.buf = buf;
     a.tab = tab;
@@ -585,6 +607,7 @@ extern "C" hipError_t mrz_launch_sequencer(hipStream_t stream, const uint8_t *bu
     a.st = st;
     a.gmailbox = gmailbox;
     a.xcd = xcd & 7;
+    a.deep_bits = deep_bits;
 #if MRZ_HELPER_WGS == 0
     n_helpers = 0;
 #endif

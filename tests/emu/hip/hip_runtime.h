@@ -88,6 +88,9 @@ static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { unsigned o = *p; if (o == cmp) *p = v; return o; }
 static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long cmp, unsigned long long v) { unsigned long long o = *p; if (o == cmp) *p = v; return o; }
+static inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMin(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
 // ---- runtime API subset -----------------------------------------------------

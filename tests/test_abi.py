@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.mrz_abi_version() == 3
+    assert lib.mrz_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_device():

@@ -85,6 +85,25 @@ def test_sequencer_workgroups_take_turns(emu_lib, oracle, wgs, monkeypatch):
     _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 19, seed=4), level=1, table=True)
 
 
+def test_deep_engine_alone(emu_lib, oracle, monkeypatch):
+    """MRZ_SEQ_ENGINE=deep: every segment on the deep engine (run scans by all waves, in-order commit with the precise
+    staleness rule, stale lanes scanned again, cooperative path for real matches): before the first cull (no lane is
+    scanned), through culling and several mask promotions at level 1 (2 MiB table: long runs), noise, text, repeats,
+    evictions (many equal tags), duplicates with backward extension."""
+    monkeypatch.setenv("MRZ_SEQ_ENGINE", "deep")
+    want = _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(3 << 20, seed=3), level=1, table=True)
+    assert want["min_mask"] > 15 and want["stats"]["inserts"] > want["hash_count"]
+    _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 20, seed=4), level=1, table=True)
+    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(400000, seed=4), level=1, table=True)
+    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(160000, seed=4), table=True)
+    _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(100000, seed=3), table=True, victim_round=7)
+    _parity.check_chunk(emu_lib, oracle, _util.rep64k(24, seed=9, period=2048), victim_round=3)
+    _parity.check_chunk(emu_lib, oracle, _util.rep64k(40, seed=9, period=997), level=2, table=True)
+    blk = _util.xorshift_noise(70000, seed=12)
+    _parity.check_chunk(emu_lib, oracle, blk + blk + b"xyz" + blk[5:])
+    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(70000, seed=4), seg_positions=4096, cand_cap=4096)
+
+
 @pytest.mark.parametrize("engine", ["wide", "narrow"])
 def test_front_end_passes_and_full_lists(emu_lib, oracle, engine, monkeypatch):
     """The candidate list of the front end: several passes per chunk (small spans), passes cut short because the list is

@@ -29,7 +29,7 @@ def inputs():
 def test_native_library_is_loaded(gpu_lib):
     import torch
     assert torch.cuda.is_available()
-    assert gpu_lib.mrz_abi_version() == 3
+    assert gpu_lib.mrz_abi_version() == 4
     assert os.path.basename(m.lib_path()) == "libmrzgpu.so"
     with open("/proc/self/maps") as f:
         assert "libmrzgpu.so" in f.read()
@@ -435,9 +435,9 @@ def test_tar_like_1gib_bit_exact_vs_oracle(gpu_lib, oracle):
     _exact_vs_oracle(gpu_lib, oracle, w.tar_like_fast(1 << 30, seed=11))
 
 
-@pytest.mark.parametrize("engine", ["wide", "narrow"])
+@pytest.mark.parametrize("engine", ["wide", "narrow", "deep"])
 def test_both_engines_pinned(gpu_lib, oracle, engine, monkeypatch):
-    """Every shape through each of the two sequencer kernels alone (MRZ_SEQ_ENGINE pins the per-segment choice)."""
+    """Every shape through each of the three sequencer kernels alone (MRZ_SEQ_ENGINE pins the per-segment choice)."""
     monkeypatch.setenv("MRZ_SEQ_ENGINE", engine)
     _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(12 << 20, seed=3), table=True)
     _parity.check_chunk(gpu_lib, oracle, _util.xorshift_noise(24 << 20, seed=5), table=True)

@@ -36,6 +36,8 @@ if "text4" in which: run("text-4MiB", w.zipf_text(4 << 20))
 if "text32" in which: run("text-32MiB", w.zipf_text(32 << 20))
 if "text100" in which: run("text-100MB", w.zipf_text(100_000_000))
 if "noise64" in which: run("noise-64MiB", w.noise(64 << 20))
+if "noise1g" in which: run("noise-1GiB", w.noise_device(1 << 30, "cuda"))
+if "noise2g" in which: run("noise-2GiB", w.noise_device(2 << 30, "cuda"))
 if "rep64" in which: run("rep64k-64MiB", w.rep64k_device(1024, "cuda"))
 if "rep1g" in which: run("rep64k-1GiB", w.rep64k_device(16384, "cuda"))
 if "rep10g" in which: run("rep64k-10GiB", w.rep64k_device(163840, "cuda"))
