@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- rzip-stage throughput of libmrzgpu on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--mode streams|window]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tar|rep64k] [--gib G] [--mode streams|window]
 
-A "step" is one pass of the rzip stage (mrz_rzip_chunk: tag scan -> sequencer ->
+A "step" is one pass of the rzip stage (mrz_rzip_chunk: front end -> sequencer ->
 record encoder, + CRC-32) over one chunk that is already resident in HBM.  The
-workload is BASELINE.json configs[1]: `mrzip -n -L7` on 10 GiB of synthetic text
-with 64 KiB-period repeats (S2 "rep64k-10G"), one chunk (-m pinned
-so max_chunk >= file size).  With N > 1 every rank runs its own 10 GiB stream on
-its own GPU (chunks / files are independent units of the reference: N `mrzip`
-processes), so scaling is weak and there is no data-path collective.
+metric of BASELINE.json is quoted on a 256 GiB window, which does not fit one
+GPU beside its literal stream; the workload is therefore the largest single-GPU
+configuration, configs[2]: the rzip stage of `mrzip -L7` on a 64 GiB synthetic
+tar (S3 mix of SURVEY.md 8d: 60 % text members, 25 % noise members, 15 % exact
+duplicates, 512-byte aligned), one chunk (-m pinned so max_chunk >= file size).
+--workload rep64k runs configs[1] instead (10 GiB of text with 64 KiB-period
+repeats; it is also one of the `shapes`).  With N > 1 every rank runs its own
+stream on its own GPU (chunks / files are independent units of the reference: N
+`mrzip` processes), so scaling is weak and there is no data-path collective.
 --mode window (N > 1) instead splits ONE window over the ranks: range-sharded tag
 scan, tags sent to rank 0 over RCCL, exact matcher on rank 0 (shard.rzip_chunk_window);
 strong scaling of a front end whose back end (the matcher) does not shard.
@@ -51,12 +55,15 @@ def _sha(b):
     return hashlib.sha256(b).hexdigest()[:16]
 
 
-def cpu_baseline(ctx, sample_bytes):
+def cpu_baseline(ctx, sample_bytes, data=None, what="rep64k"):
     """Times the oracle's rzip stage (1 core) on the first sample_bytes of the workload, with the 8-byte and the
     byte-wise match extension, and checks that a GPU run of the same prefix gives the same two streams."""
     from modern_rzip_amd import workloads
     o = _oracle()
-    data = workloads.rep64k(sample_bytes // 65536, seed=1234)
+    if data is None:
+        data = workloads.rep64k(sample_bytes // 65536, seed=1234)
+    else:
+        data = data[:sample_bytes].cpu().numpy().tobytes()  # the same bytes the GPU has sequenced
     t0 = time.perf_counter()
     r = o.rzip_chunk(data, level=7)
     dt = time.perf_counter() - t0
@@ -71,7 +78,7 @@ def cpu_baseline(ctx, sample_bytes):
     if not same:
         raise SystemExit("cpu_baseline: the GPU streams of the prefix differ from the oracle's")
     return {"value": round(len(data) / GIB / dt, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": f"first {len(data) / GIB:.2f} GiB of the same rep64k stream, oracle/liboracle.so "
+            "sample": f"first {len(data) / GIB:.2f} GiB of the same {what} stream, oracle/liboracle.so "
                       f"mrzo_rzip_chunk (matcher + CRC32, no MD5), {dt:.1f} s",
             "bytewise_value": round(len(data) / GIB / dtb, 5),
             "bytewise_note": "the same with single_match_len's byte-at-a-time compare (src/rzip.c:378) instead of 8 bytes",
@@ -103,6 +110,8 @@ def shape_line(ctx, name, data, oracle_sample=None):
     dt = time.perf_counter() - t0
     tm = ctx.timings()
     sample = data if oracle_sample is None else data[:oracle_sample]
+    if hasattr(sample, "data_ptr"):
+        sample = sample.cpu().numpy().tobytes()
     t0 = time.perf_counter()
     o.rzip_chunk(sample, level=7)
     odt = time.perf_counter() - t0
@@ -112,6 +121,7 @@ def shape_line(ctx, name, data, oracle_sample=None):
             "oracle_GiBps": round(len(sample) / GIB / odt, 5), "oracle_sample_bytes": len(sample),
             "gpu_over_oracle": round((len(data) / dt) / (len(sample) / odt), 3),
             "sequencer_ms": round(tm.sequencer_ms, 2), "launches": tm.n_segments, "narrow_launches": tm.n_narrow,
+            "deep_launches": tm.n_deep,
             "roofline_frac": round(alg / seq_s / 1e9 / HBM_PEAK_GBPS, 6) if seq_s > 0 else None,
             "matches": res.stats.matches}
 
@@ -121,7 +131,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=10.0, help="chunk size per GPU in GiB (BASELINE config: 10)")
+    ap.add_argument("--workload", default="tar", choices=["tar", "rep64k"],
+                    help="tar: BASELINE configs[2] (64 GiB synthetic tar, the largest single-GPU configuration); rep64k: "
+                         "configs[1] (10 GiB text with 64 KiB-period repeats)")
+    ap.add_argument("--gib", type=float, default=0.0, help="chunk size per GPU in GiB (default: 64 for tar, 10 for rep64k)")
     ap.add_argument("--level", type=int, default=7)
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,9 +176,19 @@ def main():
     if args.mode == "window" and world > 1:
         return window_mode(args, m, workloads, lib, dist, rank, world, dev_index)
 
+    if args.gib <= 0:
+        args.gib = 64.0 if args.workload == "tar" else 10.0
     nper = int(args.gib * GIB) // 65536
     n = nper * 65536
-    data = workloads.rep64k_device(nper, dev, seed=1234 + rank)  # every rank its own stream
+    if args.workload == "tar":
+        data = workloads.tar_like_device(n, dev, seed=5 + rank)  # every rank its own stream
+        wl_name = (f"tar-{args.gib:g}G: rzip stage of mrzip -L{args.level} on a {args.gib:g} GiB synthetic tar (60 % text members, 25 % "
+                   f"noise, 15 % exact duplicates, 512-byte aligned; BASELINE configs[2], the largest single-GPU "
+                   f"configuration), one chunk per GPU, input resident in HBM")
+    else:
+        data = workloads.rep64k_device(nper, dev, seed=1234 + rank)
+        wl_name = (f"rep64k-{args.gib:g}G: mrzip -n -L{args.level}, {args.gib:g} GiB synthetic text with 64 KiB-period "
+                   f"repeats (BASELINE configs[1]), one chunk per GPU, input resident in HBM")
     torch.cuda.synchronize()
 
     ctx = m.RzipContext(level=args.level, max_chunk=n, device=dev_index, lib=lib)
@@ -184,7 +207,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     seq_ms = tag_ms = enc_ms = crc_ms = 0.0
-    nseg = nnarrow = 0
+    nseg = nnarrow = ndeep = 0
     for _ in range(args.steps):
         ctx.victim_round = 0  # each step = a fresh `mrzip` process on the same file
         res, _, _ = ctx.rzip_chunk(data, fetch=False)  # returns after the device work has completed
@@ -193,7 +216,7 @@ def main():
         tag_ms += t.tagscan_ms
         enc_ms += t.encode_ms
         crc_ms += t.crc_ms
-        nseg, nnarrow = t.n_segments, t.n_narrow
+        nseg, nnarrow, ndeep = t.n_segments, t.n_narrow, t.n_deep
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -237,14 +260,14 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"rep64k-{args.gib:g}G: mrzip -n -L{args.level}, {args.gib:g} GiB synthetic text with "
-                                   f"64 KiB-period repeats (BASELINE configs[1]), one chunk per GPU, input resident in HBM",
-                       "level": args.level, "chunk_bytes_per_gpu": n, "streams": world, "mode": "streams"},
-            "roofline": {"bound": "hbm", "kernel": "mrz_seq_narrow_kernel" if nnarrow * 2 > nseg else "mrz_sequencer_kernel",
+            "config": {"workload": wl_name, "level": args.level, "chunk_bytes_per_gpu": n, "streams": world, "mode": "streams"},
+            "roofline": {"bound": "hbm", "kernel": "mrz_seq_narrow_kernel" if nnarrow * 2 > nseg else
+                         ("mrz_seq_deep_kernel" if ndeep * 2 > nseg else "mrz_sequencer_kernel"),
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": pmc_traffic(), "traffic_source": "profiles (rocprofv3 --pmc passes, not this run)",
-                         "launches_per_step": nseg, "narrow_launches_per_step": nnarrow, "alg_bytes_per_step": alg_bytes,
+                         "launches_per_step": nseg, "narrow_launches_per_step": nnarrow, "deep_launches_per_step": ndeep,
+                         "alg_bytes_per_step": alg_bytes,
                          "avg_launch_ms": round(seq_ms / steps / max(nseg, 1), 4)},
             "kernel_ms_per_step": {"sequencer": round(seq_ms / steps, 2), "tagscan": round(tag_ms / steps, 2),
                                    "encode": round(enc_ms / steps, 2), "crc32": round(crc_ms / steps, 2)},
@@ -253,7 +276,7 @@ def main():
         }
         if verify:
             out["verify"] = verify
-        if world == 1 and args.gib > 4.5:
+        if world == 1 and args.gib > 4.5 and args.workload == "rep64k":
             # the S2 generator repeats itself exactly after 4 GiB (period i + 65536 equals period i): the tail of the
             # chunk is ONE match.  Time the part that carries the matcher's work on its own.
             n4 = 4 * GIB
@@ -268,18 +291,32 @@ def main():
                             "us_per_emitted_match_first_4GiB": round(d4 * 1e6 / max(r4.n_events, 1), 2),
                             "tail_GiBps": round((n - n4) / GIB / max(step_s - d4, 1e-9), 2),
                             "note": "beyond 4 GiB the stream repeats itself exactly: the tail is one match"}
+        base = None
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
+            if args.workload == "tar":
+                base = cpu_baseline(ctx, int(min(args.cpu_sample_gib, args.gib) * GIB), data=data, what="tar")
+            else:
+                base = cpu_baseline(ctx, int(min(args.cpu_sample_gib, args.gib) * GIB))
         if not args.no_shapes and world == 1:
             del data
             torch.cuda.empty_cache()
             shapes = []
-            with m.RzipContext(level=args.level, max_chunk=256 << 20, device=dev_index, lib=lib) as c2:
+            with m.RzipContext(level=args.level, max_chunk=1 << 30, device=dev_index, lib=lib) as c2:
                 c2.set_profiling(True)
                 shapes.append(shape_line(c2, "text-100M (S1, shape of configs[0])", workloads.zipf_text(100_000_000)))
                 shapes.append(shape_line(c2, "noise-64M", workloads.noise(64 << 20)))
+                shapes.append(shape_line(c2, "noise-1G", workloads.noise_device(1 << 30, dev, seed=11)))
                 shapes.append(shape_line(c2, "tar-like-128M (S3 mix, shape of configs[2])", workloads.tar_like(128 << 20)))
+            if args.workload == "tar":
+                ctx.close()  # (frees the 64 GiB chunk's scratch)
+                with m.RzipContext(level=args.level, max_chunk=10 * GIB, device=dev_index, lib=lib) as c3:
+                    c3.set_profiling(True)
+                    shapes.append(shape_line(c3, "rep64k-10G (BASELINE configs[1]; beyond 4 GiB the stream repeats itself: the tail "
+                                                 "is one match)", workloads.rep64k_device(10 * GIB // 65536, dev, seed=1234),
+                                             oracle_sample=2 * GIB))
             out["shapes"] = shapes
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(ctx, int(min(args.cpu_sample_gib, args.gib) * GIB))
+        if base is not None:
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

@@ -136,7 +136,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         if (e && !strcmp(e, "wide")) ctx->engine_pin = 1;
         if (e && !strcmp(e, "narrow")) ctx->engine_pin = 2;
         if (e && !strcmp(e, "deep")) ctx->engine_pin = 3;
-        ctx->deep_min_bits = 7;
+        ctx->deep_min_bits = 6;
         if (const char *d = getenv("MRZ_DEEP_MIN_BITS")) ctx->deep_min_bits = atoi(d);
         e = getenv("MRZ_PRINT_PROF");
         if (e) ctx->print_prof = !strcmp(e, "narrow") ? 2 : 1;

@@ -18,7 +18,8 @@ def run(name, data, level=7):
     n = t.numel()
     with m.RzipContext(level=level, max_chunk=n, lib=LIB) as ctx:
         ctx.set_profiling(True)
-        ctx.rzip_chunk(t, fetch=False)
+        if not PROF:
+            ctx.rzip_chunk(t, fetch=False)
         t0 = time.perf_counter()
         res, _, _ = ctx.rzip_chunk(t, fetch=False)
         dt = time.perf_counter() - t0
@@ -38,6 +39,8 @@ if "text100" in which: run("text-100MB", w.zipf_text(100_000_000))
 if "noise64" in which: run("noise-64MiB", w.noise(64 << 20))
 if "noise1g" in which: run("noise-1GiB", w.noise_device(1 << 30, "cuda"))
 if "noise2g" in which: run("noise-2GiB", w.noise_device(2 << 30, "cuda"))
+if "noise8g" in which: run("noise-8GiB", w.noise_device(8 << 30, "cuda"))
+if "tar8g" in which: run("tar-8GiB", w.tar_like_device(8 << 30, "cuda"))
 if "rep64" in which: run("rep64k-64MiB", w.rep64k_device(1024, "cuda"))
 if "rep1g" in which: run("rep64k-1GiB", w.rep64k_device(16384, "cuda"))
 if "rep10g" in which: run("rep64k-10GiB", w.rep64k_device(163840, "cuda"))
