@@ -560,7 +560,13 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         retired++;
         known_p = sn->p;
         known_mask = sn->min_mask;
-        if (!ctx->cand_fn) known_next = sn->scan_next;
+        if (!ctx->cand_fn)
+            known_next = sn->scan_next;
+        else if (sn->seg_end > sn->seg_start && sn->scan_next < sn->seg_end)
+            // (window sharding, where the host drives the geometry: the wide engine has ended this launch where the mask
+            // reached the deep engine's regime and taken scan_next back to its position -- the next stretch is asked for
+            // from there)
+            known_next = sn->scan_next;
         hint_pos = sn->hint_positions;
         hint_matched = sn->hint_matched;
         if (ctx->progress_fn) {

@@ -44,6 +44,9 @@
 #endif
 #define MRZ_SEQ_WAVES MRZ_DEEP_WAVES
 #include "mrz_seq_common.h"
+#ifdef MRZ_DEEP_TRACE
+#include <stdio.h>
+#endif
 
 #ifndef MRZ_DEEP_LANES
 #define MRZ_DEEP_LANES 256  // lanes of a batch
@@ -60,10 +63,12 @@
 #endif
 #define MRZ_DEEP_MAP 2048      // entries of the two maps of planned writes (slots, tags)
 #define MRZ_DEEP_CW_WORDS 32   // cull window: 32 x 64 slots ahead of tag_clean_ptr
+#define MRZ_DEEP_XW 192        // slots written by cooperative-path candidates inside one batch (beyond: the batch is cut)
 
 enum { MRZ_DK_NONE = 255, MRZ_DK_EMPTY = 0, MRZ_DK_OVER = 1, MRZ_DK_DISPLACE = 2, MRZ_DK_EVICT = 3 };
 #define MRZ_DF_INS 1
 #define MRZ_DF_CPLX 2
+#define MRZ_DF_STALE 4   // an earlier lane that has committed since touched what the scan depends on: scan again
 // why a lane stops a round
 #define MRZ_DS_COOP 1      // needs the cooperative path (a real match, a cascade, too many tag-equal entries, a write into the cull window)
 #define MRZ_DS_CONFLICT 2  // an earlier lane of the round touches what its scan depends on
@@ -83,6 +88,9 @@ struct mrz_deep_lds {
     int idx[MRZ_DEEP_LANES];                                  // its entry of the candidate list
     int h[MRZ_DEEP_LANES], fe[MRZ_DEEP_LANES], w[MRZ_DEEP_LANES], h2[MRZ_DEEP_LANES], w2[MRZ_DEEP_LANES];
     int cmin[MRZ_DEEP_LANES];                                 // first lane of the round that touches what this one depends on
+    unsigned short xw_seen[MRZ_DEEP_LANES];                   // cooperative-path writes of this batch the lane's scan has seen
+    int xw_n;                                                 // slots the cooperative path has written in this batch
+    int xw_slot[MRZ_DEEP_XW];
     unsigned char kind[MRZ_DEEP_LANES], kind2[MRZ_DEEP_LANES], nsame[MRZ_DEEP_LANES], flags[MRZ_DEEP_LANES];
     unsigned short rescan_list[MRZ_DEEP_LANES];
     int same_slot[MRZ_DEEP_LANES][MRZ_SMAX];
@@ -233,7 +241,7 @@ static_assert(MRZ_DEEP_CW_WORDS == 32, "mrz_deep_cw_slot searches 32 words in 5 
 
 // ---- SCAN of one lane by one wave ---------------------------------------------------------------------------------
 __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, int64_t better, int64_t tag_mask,
-                                     int64_t clean_ptr, int lane) {
+                                     int64_t clean_ptr, int xw_n, int lane) {
     const mrz_slot *tab = C.tab;
     const uint8_t *__restrict__ buf = C.buf;
     const int smask = (int)C.slot_mask;
@@ -373,6 +381,7 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
         S->nsame[i] = (unsigned char)ns;
         S->flags[i] = (unsigned char)((ins ? MRZ_DF_INS : 0) | (cplx ? MRZ_DF_CPLX : 0));
         S->cp_scan[i] = clean_ptr;
+        S->xw_seen[i] = (unsigned short)xw_n;
     }
 }
 
@@ -543,12 +552,13 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
         PROF_ADD(MRZ_ST_D_T_FORM);
         // ---- SCAN --------------------------------------------------------------------------------------------------
         if (!loose)
-            for (int i = wave; i < nb; i += MRZ_DEEP_WAVES) mrz_deep_scan(C, S, i, better, L.tag_mask, L.clean_ptr, lane);
+            for (int i = wave; i < nb; i += MRZ_DEEP_WAVES) mrz_deep_scan(C, S, i, better, L.tag_mask, L.clean_ptr, 0, lane);
         __syncthreads();
         PROF_ADD(MRZ_ST_D_T_SCAN);
         // ---- COMMIT: rounds ------------------------------------------------------------------------------------------
         int next = 0;       // first lane not dealt with
-        bool cut = false;   // the rest of the batch is void (cooperative path): form again
+        bool cut = false;   // the rest of the batch is void (the masks have moved): form again
+        int xw_n = 0;       // slots the cooperative path has written since the batch was scanned (S->xw_slot)
         while (next < nb && !cut && ok) {
             const int i = tid;  // this thread's lane
             const bool mine = i >= next && i < nb;
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                             m = mrz_deep_tmap_get(S, occ_t);
                             if (m != i) cmin = m < cmin ? m : cmin;
                         }
-                        if (cmin < i) stop |= MRZ_DS_CONFLICT;
+                        if (cmin < i || (f & MRZ_DF_STALE)) stop |= MRZ_DS_CONFLICT;
                         // a real match (or a compare beyond the 64-byte reach) among the tag-equal entries
                         const int ns = S->nsame[i];
                         const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
@@ -620,6 +630,12 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         // a store that takes a failing entry out of the sweep's way changes which entries later culls find
                         if (wr_w && kind == MRZ_DK_OVER && w >= cw_base && w < cw_base + cw_len) stop |= MRZ_DS_COOP;
                         if (wr_w2 && kind2 == MRZ_DK_OVER && w2 >= cw_base && w2 < cw_base + cw_len) stop |= MRZ_DS_COOP;
+                        // a slot the cooperative path has written since the scan, inside what the lane has read
+                        for (int k = S->xw_seen[i]; k < xw_n; k++) {
+                            const int xs = S->xw_slot[k];
+                            if ((((xs - h) & smask) <= ((fe - h) & smask)) || (wr_w2 && (((xs - h2) & smask) <= ((w2 - h2) & smask))))
+                                stop |= MRZ_DS_CULLED;
+                        }
                         // culled since the scan (by earlier rounds / batches)?
                         const int64_t cp0 = S->cp_scan[i];
                         if (L.clean_ptr != cp0) {
@@ -688,7 +704,14 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 }
                 const int e2 = mrz_deep_first(inb && stop != 0, S->wmin2, lane, wave, tid, e1);
                 if (mine && i == e2) S->ctl[4] = stop;
+                // a lane behind the committed ones that depends on what one of them has written stays marked until it has
+                // been scanned again (the round may end in the cooperative path, and the next one only knows ITS lanes' plans)
+                if (mine && i >= e2 && cmin < e2) S->flags[i] = (unsigned char)(f | MRZ_DF_STALE);
                 // R6: lanes [next, e2) commit as scanned (insert_hash + clean_one_from_hash, src/rzip.c:256-328,579-584)
+#ifdef MRZ_DEEP_TRACE
+                if (mine && i < e2 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
+                    printf("bulk q=%lld ins=%d kind=%d w=%d w2=%d cslot=%d nsame=%d lane=%d next=%d e2=%d\n", (long long)q, (int)a_ins, kind, w, w2, cslot, (int)S->nsame[i], i, next, e2);
+#endif
                 if (mine && i < e2) {
                     if (a_ins) {
                         int ws = w;
@@ -759,7 +782,15 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         // once, against the table as it is now
                         bool again = false;
                         if (i >= next && i < nb && !(S->flags[i] & MRZ_DF_CPLX)) {
-                            again = S->cmin[i] < next;
+                            again = (S->flags[i] & MRZ_DF_STALE) != 0;
+                            {
+                                const int hh = S->h[i], ff = S->fe[i], hh2 = S->h2[i], ww2 = S->w2[i];
+                                const bool dsp = (S->flags[i] & MRZ_DF_INS) && S->kind[i] == MRZ_DK_DISPLACE;
+                                for (int k = S->xw_seen[i]; k < xw_n && !again; k++) {
+                                    const int xs = S->xw_slot[k];
+                                    again = (((xs - hh) & smask) <= ((ff - hh) & smask)) || (dsp && (((xs - hh2) & smask) <= ((ww2 - hh2) & smask)));
+                                }
+                            }
                             if (!again) {
                                 const int64_t cp0 = S->cp_scan[i];
                                 if (L.clean_ptr != cp0) {
@@ -781,41 +812,67 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         ST_ADD(MRZ_ST_D_ROUNDS, 1);
                         ST_ADD(MRZ_ST_D_RESCANNED, nr);
                         for (int k = wave; k < nr; k += MRZ_DEEP_WAVES)
-                            mrz_deep_scan(C, S, (int)S->rescan_list[k], better, L.tag_mask, L.clean_ptr, lane);
+                            mrz_deep_scan(C, S, (int)S->rescan_list[k], better, L.tag_mask, L.clean_ptr, xw_n, lane);
                         __syncthreads();
                         PROF_ADD(MRZ_ST_D_T_RESCAN);
                     }
                 }
             }
             if (coop_lane >= 0) {
-                // one candidate through the cooperative path (wave 0): exact, any chain / match length, mask promotion
+                // one candidate through the cooperative path (wave 0): exact, any chain / match length, mask promotion.  Its
+                // stores (the insert's write-back list, the cull) go on the list of slots the lanes behind it have to check
+                // their scans against; a match it emits carries the matcher over the lanes it covers.
                 if (wave == 0) {
                     const int64_t q = mrz_uni64(S->q[coop_lane]), t = mrz_uni64(S->t[coop_lane]);
-                    const int64_t ev0 = L.n_events, mm0 = L.min_mask, tm0 = L.tag_mask;
+                    const int64_t mm0 = L.min_mask, tm0 = L.tag_mask;
                     L.p = q;
                     const bool okc = mrz_seq_candidate(C, L, &S->coop, t, lane, stat);
-                    // before the first cull the batch goes on, one candidate at a time, for as long as nothing else changes
-                    const bool go_on = okc && loose && L.n_events == ev0 && L.min_mask == mm0 && L.tag_mask == tm0 && L.cur_len == 0;
+#ifdef MRZ_DEEP_TRACE
+                    if (lane == 0 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
+                        printf("coop q=%lld -> p=%lld ev=%lld cur_len=%lld nw=%d lane=%d\n", (long long)q, (long long)L.p, (long long)L.n_events, (long long)L.cur_len, S->coop.n_written, coop_lane);
+#endif
+                    const bool same_masks = L.min_mask == mm0 && L.tag_mask == tm0;
+                    int nx = xw_n;
+                    const int nwr = mrz_uni(S->coop.n_written);
+                    const int64_t cs = mrz_uni64(S->coop.cull_slot);
+                    const bool room = nx + nwr + 1 <= MRZ_DEEP_XW;
+                    if (okc && same_masks && room && !loose) {
+                        if (lane < nwr) S->xw_slot[nx + lane] = (int)S->coop.pend_h[lane];
+                        nx += nwr;
+                        if (cs >= 0) {
+                            if (lane == 0) S->xw_slot[nx] = (int)cs;
+                            nx++;
+                        }
+                    }
                     if (lane == 0) {
                         S->lead = L;
-                        S->ctl[0] = okc ? (go_on ? 1 : 2) : 3;
+                        // (a match that ends BEFORE the emitting position takes the loop's p back, src/rzip.c:596: the
+                        // candidates behind its end run again -- the batch is formed again from there)
+                        S->ctl[0] = !okc ? 3 : ((same_masks && (room || loose) && L.p >= q) ? 1 : 2);
+                        S->ctl[5] = nx;
                     }
                     MRZ_DEEP_WAIT();
                 }
                 __syncthreads();
                 L = S->lead;
+                xw_n = mrz_uni(S->ctl[5]);
                 const int v = mrz_uni(S->ctl[0]);
                 ST_ADD(MRZ_ST_D_COOP, 1);
-                next = coop_lane + 1;
                 if (v == 3) ok = false;
                 if (v == 2) cut = true;
-                __syncthreads();
+                // the first lane behind the matcher's position (an emitted match covers the lanes inside it)
+                {
+                    const int i = tid;
+                    const int nf = mrz_deep_first(i > coop_lane && i < nb && S->q[i] > L.p, S->wmin3, lane, wave, tid, nb);
+                    next = nf;
+                }
                 PROF_ADD(MRZ_ST_D_T_RESCAN);
             }
         }
-        // where the next batch begins
+        // where the next batch begins: behind the entries this one has covered -- or, when the masks have moved or a match
+        // has carried the matcher beyond them, at the first entry behind its position
         if (ok) {
-            if (cut) {
+            if (cut || L.p > mrz_uni64(S->q[nb - 1])) {
                 int64_t pos = L.p + 1;
                 if (pos < K.seg_start) pos = K.seg_start;
                 ci = mrz_cand_lower_bound(K, pos, lane);

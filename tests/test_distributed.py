@@ -118,6 +118,26 @@ def test_two_ranks_over_gloo(emu_lib, oracle):
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
 
 
+def test_provider_path_when_the_wide_engine_hands_over_to_the_deep_one(emu_lib, oracle, monkeypatch):
+    """Candidate provider + engine change inside a stretch: at level 1 the mask tightens quickly; the wide engine ends
+    its launch where the mask reaches MRZ_DEEP_MIN_BITS and takes scan_next back to its position -- the host (which
+    drives the geometry in this mode) must ask for the next stretch from THERE, not from where the last one ended."""
+    import modern_rzip_amd as m
+    from tests import _util
+    monkeypatch.setenv("MRZ_DEEP_MIN_BITS", "5")
+    data = _util.xorshift_noise(3400000, seed=3)
+    want = oracle.rzip_chunk(data, level=1)
+    assert want["min_mask"] >= 31
+    with m.RzipContext(lib=emu_lib, level=1, max_chunk=len(data)) as ctx, m.RzipContext(lib=emu_lib, level=1, max_chunk=len(data)) as other:
+        def provider(seg_start, span, min_mask, p_done, cap):
+            return other.window_scan(data, 0, len(data), seg_start, span, min_mask, p_done, cap=cap)
+        ctx.set_cand_provider(provider)
+        res, s0, s1 = ctx.rzip_chunk(data)
+        ctx.set_cand_provider(None)
+        assert (s0, s1) == (want["s0"], want["s1"]) and res.stats.as_dict() == want["stats"]
+        assert ctx.timings().n_deep >= 1 and ctx.timings().n_deep < ctx.timings().n_segments
+
+
 def run_window_workers(which, segments, seg_bytes, timeout=600, backend="gloo"):
     """Two FRESH processes (started before anything in them touches a device), one rank each, over the window-sharded
     path with peer-mapped window memory: tests/_window_worker.py.  Returns rank 0's output."""
