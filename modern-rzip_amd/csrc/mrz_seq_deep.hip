@@ -385,6 +385,78 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
     }
 }
 
+// One candidate whose scan still holds, replayed by wave 0 FROM ITS RECORD instead of walking the table again: the
+// tag-equal entries are measured exactly (64-byte probes per lane, long ones by the striped path / the compare farm:
+// mrz_resolve_entries) and folded in probe order (find_best_match, src/rzip.c:443-454), the insert lands where the scan
+// found its place (insert_hash :256-301), the cull is the generic sweep step (:305-328), then the lazy selection and the
+// emit rule (:586-599).  For lanes with a real match among their entries -- the table walk of the cooperative path is
+// what costs at long runs.  Appends the slots it writes to S->xw_slot[*xw_n ...]; false on event-list overflow.
+__device__ static bool mrz_deep_candidate_rec(const mrz_cfg &C, mrz_lead &L, mrz_deep_lds *S, int i, int *xw_n, int lane,
+                                              int64_t *stat) {
+    mrz_coop_lds *B = &S->coop;
+    const int64_t q = mrz_uni64(S->q[i]), t = mrz_uni64(S->t[i]);
+    const int ns = mrz_uni((int)S->nsame[i]);
+    const int f = mrz_uni((int)S->flags[i]);
+    int64_t mlen = 0, m_off = 0, m_rev = 0;
+    L.p = q;
+    if (ns) {
+        if (lane < ns) {
+            const int64_t op = S->same_off[i][lane];
+            B->same_off[lane] = op;
+            int64_t ml, rv;
+            bool lng;
+            mrz_lane_match_len(C.buf, q, op, C.end, L.last_match, &ml, &rv, &lng);
+            B->pair_res[lane] = lng ? -1 : (int)((ml << 8) | rv);
+        }
+        MRZ_WAVE_SYNC();
+        int xh = 0, xm = 0;
+        if (!mrz_resolve_entries(C, L, B, q, ns, lane, stat, &mlen, &m_off, &m_rev, &xh, &xm)) return false;
+        L.tag_hits += xh;
+        L.tag_misses += xm;
+    }
+    int nx = *xw_n;
+    if (f & MRZ_DF_INS) {
+        const int kind = mrz_uni((int)S->kind[i]);
+        L.inserts++;
+        L.count++;
+        int ws = mrz_uni(S->w[i]);
+        if (kind == MRZ_DK_OVER)
+            L.count--;
+        else if (kind == MRZ_DK_EVICT) {
+            L.count--;
+            ws = mrz_uni(S->same_slot[i][(int)L.victim_round]);
+            L.victim_round = L.victim_round + 1 == C.max_chain ? 0 : L.victim_round + 1;
+        } else if (kind == MRZ_DK_DISPLACE) {
+            const int w2 = mrz_uni(S->w2[i]);
+            if (mrz_uni((int)S->kind2[i]) == MRZ_DK_OVER) L.count--;
+            if (lane == 0) {
+                mrz_slot oc;
+                oc.off = S->occ_off[i];
+                oc.t = S->occ_t[i];
+                C.tab[w2] = oc;
+                S->xw_slot[nx] = w2;
+            }
+            nx++;
+        }
+        if (lane == 0) {
+            mrz_slot nw;
+            nw.off = q;
+            nw.t = t;
+            C.tab[ws] = nw;
+            S->xw_slot[nx] = ws;
+        }
+        nx++;
+        if (L.count > C.limit) {
+            MRZ_DEEP_WAIT();  // (the stores above, before the sweep reads the table)
+            mrz_cull_one(C, L, lane);
+            if (lane == 0) S->xw_slot[nx] = (int)L.clean_ptr;
+            nx++;
+        }
+    }
+    *xw_n = nx;
+    return mrz_select_emit(C, L, mlen, m_off, m_rev, lane);
+}
+
 // workgroup-wide inclusive prefix sum of one int per thread; *total = the sum.  One barrier; `ws` must not be reused
 // before another barrier.
 __device__ __forceinline__ int mrz_deep_incl(int v, int *ws, int lane, int wave, int *total) {
@@ -564,6 +636,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
             const bool mine = i >= next && i < nb;
             const int round_start = next;
             int coop_lane = -1;
+            bool use_record = false;  // the cooperative-path candidate is replayed from its (still valid) scan record
             if (loose || L.cur_len > 0) {
                 // before the first cull no lane has been scanned; a pending lazy match (src/rzip.c:586-599) is decided at
                 // the next candidate: the cooperative path takes it
@@ -772,10 +845,27 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 PROF_ADD(MRZ_ST_D_T_COMMIT);
                 if (next < nb) {
                     const int sf = mrz_uni(S->ctl[4]);
-                    if (sf & MRZ_DS_COOP)
+                    // (a lane that stops the round for the cooperative path AND whose scan no longer holds is scanned again
+                    // first: its record then serves the replay)
+                    bool stop_stale = (sf & (MRZ_DS_CONFLICT | MRZ_DS_CULLED)) != 0 || (S->flags[next] & MRZ_DF_STALE);
+                    if (!stop_stale && !(S->flags[next] & MRZ_DF_CPLX)) {
+                        const int64_t cp0 = S->cp_scan[next];
+                        if (L.clean_ptr != cp0) {  // culled by the lanes that have just committed?
+                            const int lc = (int)(L.clean_ptr - cp0) + 1;
+                            const int hh = S->h[next], ff = S->fe[next];
+                            stop_stale = mrz_deep_ranges_meet(hh, ((ff - hh) & smask) + 1, (int)cp0, lc, smask);
+                            if (!stop_stale && (S->flags[next] & MRZ_DF_INS) && S->kind[next] == MRZ_DK_DISPLACE) {
+                                const int hh2 = S->h2[next], ww2 = S->w2[next];
+                                stop_stale = mrz_deep_ranges_meet(hh2, ((ww2 - hh2) & smask) + 1, (int)cp0, lc, smask);
+                            }
+                        }
+                    }
+                    if ((sf & MRZ_DS_COOP) && !stop_stale) {
                         coop_lane = next;
-                    else if ((sf & MRZ_DS_NOCULL) && next == round_start) {
+                        use_record = !(S->flags[next] & MRZ_DF_CPLX);
+                    } else if ((sf & MRZ_DS_NOCULL) && next == round_start && !stop_stale) {
                         coop_lane = next;  // (the sweep has to go further than the window reaches, or to wrap: the generic step)
+                        use_record = !(S->flags[next] & MRZ_DF_CPLX);
                     } else {
                         // lanes at or behind `next` whose scan no longer holds -- an earlier lane that HAS committed touched
                         // what they depend on, or the sweep has reached into what they read -- are scanned again, all at
@@ -826,17 +916,22 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     const int64_t q = mrz_uni64(S->q[coop_lane]), t = mrz_uni64(S->t[coop_lane]);
                     const int64_t mm0 = L.min_mask, tm0 = L.tag_mask;
                     L.p = q;
-                    const bool okc = mrz_seq_candidate(C, L, &S->coop, t, lane, stat);
+                    int nx_rec = xw_n;
+                    const bool rec = use_record && xw_n + 4 <= MRZ_DEEP_XW;
+                    const bool okc = rec ? mrz_deep_candidate_rec(C, L, S, coop_lane, &nx_rec, lane, stat)
+                                         : mrz_seq_candidate(C, L, &S->coop, t, lane, stat);
 #ifdef MRZ_DEEP_TRACE
                     if (lane == 0 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
                         printf("coop q=%lld -> p=%lld ev=%lld cur_len=%lld nw=%d lane=%d\n", (long long)q, (long long)L.p, (long long)L.n_events, (long long)L.cur_len, S->coop.n_written, coop_lane);
 #endif
                     const bool same_masks = L.min_mask == mm0 && L.tag_mask == tm0;
                     int nx = xw_n;
-                    const int nwr = mrz_uni(S->coop.n_written);
-                    const int64_t cs = mrz_uni64(S->coop.cull_slot);
+                    const int nwr = rec ? 0 : mrz_uni(S->coop.n_written);
+                    const int64_t cs = rec ? -1 : mrz_uni64(S->coop.cull_slot);
                     const bool room = nx + nwr + 1 <= MRZ_DEEP_XW;
-                    if (okc && same_masks && room && !loose) {
+                    if (rec)
+                        nx = nx_rec;
+                    else if (okc && same_masks && room && !loose) {
                         if (lane < nwr) S->xw_slot[nx + lane] = (int)S->coop.pend_h[lane];
                         nx += nwr;
                         if (cs >= 0) {
