@@ -96,6 +96,7 @@ extern "C" void mrz_close(mrz_ctx *ctx) {
     hipFree(ctx->d_crc_out);
     if (ctx->d_gmailbox) hipFree(ctx->d_gmailbox);
     if (ctx->d_seq_shared) hipFree(ctx->d_seq_shared);
+    if (ctx->d_deep_shared) hipFree(ctx->d_deep_shared);
     if (ctx->d_wlog) hipFree(ctx->d_wlog);
     if (ctx->rz_scratch) hipFree(ctx->rz_scratch);
     if (ctx->d_rz_out) hipFree(ctx->d_rz_out);
@@ -203,6 +204,9 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
             rc = MRZ_E_NOMEM;
         ctx->seq_wgs = 3;
         if (const char *e = getenv("MRZ_SEQ_WGS")) ctx->seq_wgs = atoi(e);
+        if (hipMalloc(&ctx->d_deep_shared, mrz_seq_deep_shared_size()) != hipSuccess) rc = MRZ_E_NOMEM;
+        ctx->deep_scanners = 7;
+        if (const char *e = getenv("MRZ_DEEP_SCANNERS")) ctx->deep_scanners = atoi(e);
     }
     if (!rc && max_chunk > 0) {
         rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, max_chunk / MRZ_MIN_MATCH + 2);
@@ -659,7 +663,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                              ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->xcd));
         else if (deep)
             STEP(mrz_launch_sequencer_deep(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
-                                           ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->xcd));
+                                           ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->xcd, ctx->d_deep_shared,
+                                           ctx->deep_scanners));
         else
             STEP(mrz_launch_sequencer(s, d_buf, ctx->d_tab, ctx->d_cand, ctx->d_tile_off, (const mrz_u64 *)ctx->d_bitmap,
                                       ctx->d_events, ctx->d_state, ctx->d_gmailbox, helpers, ctx->d_seq_shared, ctx->d_wlog,

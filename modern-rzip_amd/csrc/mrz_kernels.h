@@ -34,7 +34,8 @@ hipError_t mrz_launch_sequencer_narrow(hipStream_t stream, const uint8_t *buf, m
                                        void *gmailbox, int n_helpers, int xcd);
 hipError_t mrz_launch_sequencer_deep(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
                                      const int *tile_off, const mrz_u64 *bitmap, mrz_event *events, mrz_seq_state *st,
-                                     void *gmailbox, int n_helpers, int xcd);
+                                     void *gmailbox, int n_helpers, int xcd, void *deep_shared, int scanners);
+size_t mrz_seq_deep_shared_size(void);
 size_t mrz_sequencer_mailbox_size(void);
 size_t mrz_seq_narrow_mailbox_size(void);
 int mrz_sequencer_default_helpers(int device);

@@ -44,6 +44,7 @@
 #endif
 #define MRZ_SEQ_WAVES MRZ_DEEP_WAVES
 #include "mrz_seq_common.h"
+#include <cstddef>
 #ifdef MRZ_DEEP_TRACE
 #include <stdio.h>
 #endif
@@ -75,27 +76,31 @@ enum { MRZ_DK_NONE = 255, MRZ_DK_EMPTY = 0, MRZ_DK_OVER = 1, MRZ_DK_DISPLACE = 2
 #define MRZ_DS_CULLED 4    // the round's culls reach into what it has read
 #define MRZ_DS_NOCULL 8    // the cull window holds no entry for it
 
+// what a scan leaves per lane (in LDS; the scan helpers' copies travel through device memory)
+struct mrz_deep_recs {
+    int64_t q[MRZ_DEEP_LANES], t[MRZ_DEEP_LANES];
+    int64_t occ_t[MRZ_DEEP_LANES], occ_off[MRZ_DEEP_LANES];  // the occupant a displacing lane moves
+    int64_t old_t[MRZ_DEEP_LANES], old_t2[MRZ_DEEP_LANES];   // tags the lane's stores overwrite (0: none)
+    int64_t cp_scan[MRZ_DEEP_LANES];                         // tag_clean_ptr when the lane was scanned
+    int h[MRZ_DEEP_LANES], fe[MRZ_DEEP_LANES], w[MRZ_DEEP_LANES], h2[MRZ_DEEP_LANES], w2[MRZ_DEEP_LANES];
+    unsigned short xw_seen[MRZ_DEEP_LANES];                   // cooperative-path writes of this batch the lane's scan has seen
+    unsigned char kind[MRZ_DEEP_LANES], kind2[MRZ_DEEP_LANES], nsame[MRZ_DEEP_LANES], flags[MRZ_DEEP_LANES];
+    int same_slot[MRZ_DEEP_LANES][MRZ_SMAX];
+    int64_t same_off[MRZ_DEEP_LANES][MRZ_SMAX];
+    unsigned short raw[MRZ_DEEP_LANES][MRZ_SMAX];             // mrz_deep_probe_raw of every tag-equal entry
+};
+
 struct mrz_deep_lds {
     mrz_lead lead;
     int ctl[16];
     int wsum[MRZ_DEEP_WAVES], wsum2[MRZ_DEEP_WAVES], wmin[MRZ_DEEP_WAVES], wmin2[MRZ_DEEP_WAVES], wmin3[MRZ_DEEP_WAVES];
     int n_rescan;
-    // per lane: what the scan found
-    int64_t q[MRZ_DEEP_LANES], t[MRZ_DEEP_LANES];
-    int64_t occ_t[MRZ_DEEP_LANES], occ_off[MRZ_DEEP_LANES];  // the occupant a displacing lane moves
-    int64_t old_t[MRZ_DEEP_LANES], old_t2[MRZ_DEEP_LANES];   // tags the lane's stores overwrite (0: none)
-    int64_t cp_scan[MRZ_DEEP_LANES];                         // tag_clean_ptr when the lane was scanned
-    int idx[MRZ_DEEP_LANES];                                  // its entry of the candidate list
-    int h[MRZ_DEEP_LANES], fe[MRZ_DEEP_LANES], w[MRZ_DEEP_LANES], h2[MRZ_DEEP_LANES], w2[MRZ_DEEP_LANES];
+    mrz_deep_recs R;
+    int idx[MRZ_DEEP_LANES];                                  // the lane's entry of the candidate list
     int cmin[MRZ_DEEP_LANES];                                 // first lane of the round that touches what this one depends on
-    unsigned short xw_seen[MRZ_DEEP_LANES];                   // cooperative-path writes of this batch the lane's scan has seen
     int xw_n;                                                 // slots the cooperative path has written in this batch
     int xw_slot[MRZ_DEEP_XW];
-    unsigned char kind[MRZ_DEEP_LANES], kind2[MRZ_DEEP_LANES], nsame[MRZ_DEEP_LANES], flags[MRZ_DEEP_LANES];
     unsigned short rescan_list[MRZ_DEEP_LANES];
-    int same_slot[MRZ_DEEP_LANES][MRZ_SMAX];
-    int64_t same_off[MRZ_DEEP_LANES][MRZ_SMAX];
-    unsigned short raw[MRZ_DEEP_LANES][MRZ_SMAX];             // mrz_deep_probe_raw of every tag-equal entry
     // what the lanes of this round PLAN to write: slot -> first lane, tag -> first lane
     unsigned smap_key[MRZ_DEEP_MAP];             // slot + 1
     int smap_lane[MRZ_DEEP_MAP];
@@ -246,7 +251,7 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
     const uint8_t *__restrict__ buf = C.buf;
     const int smask = (int)C.slot_mask;
     const int max_chain = (int)C.max_chain;
-    const int64_t q = mrz_uni64(S->q[i]), t = mrz_uni64(S->t[i]);
+    const int64_t q = mrz_uni64(S->R.q[i]), t = mrz_uni64(S->R.t[i]);
     const bool ins = (t & tag_mask) == tag_mask;
     const int my_rank = mrz_ones_rank(t);
     const int h = (int)(t & C.slot_mask);
@@ -304,8 +309,8 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
                 if ((m_same >> lane) & 1) {
                     const int k = nsame + __popcll(m_same & mrz_low_mask(lane));
                     if (k < MRZ_SMAX) {
-                        S->same_slot[i][k] = (sb + lane) & smask;
-                        S->same_off[i][k] = e[g].off;
+                        S->R.same_slot[i][k] = (sb + lane) & smask;
+                        S->R.same_off[i][k] = e[g].off;
                     }
                 }
                 nsame += __popcll(m_same);
@@ -364,24 +369,160 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
     const int ns = nsame < MRZ_SMAX ? nsame : MRZ_SMAX;
     if (ns) {
         MRZ_WAVE_SYNC();
-        if (lane < ns) S->raw[i][lane] = (unsigned short)mrz_deep_probe_raw(buf, q, S->same_off[i][lane], C.end);
+        if (lane < ns) S->R.raw[i][lane] = (unsigned short)mrz_deep_probe_raw(buf, q, S->R.same_off[i][lane], C.end);
     }
     if (lane == 0) {
-        S->h[i] = h;
-        S->fe[i] = fe;
-        S->w[i] = w;
-        S->kind[i] = (unsigned char)(kind < 0 ? MRZ_DK_NONE : kind);
-        S->h2[i] = h2;
-        S->w2[i] = w2;
-        S->kind2[i] = (unsigned char)kind2;
-        S->occ_t[i] = occ_t;
-        S->occ_off[i] = occ_off;
-        S->old_t[i] = old_t;
-        S->old_t2[i] = old_t2;
-        S->nsame[i] = (unsigned char)ns;
-        S->flags[i] = (unsigned char)((ins ? MRZ_DF_INS : 0) | (cplx ? MRZ_DF_CPLX : 0));
-        S->cp_scan[i] = clean_ptr;
-        S->xw_seen[i] = (unsigned short)xw_n;
+        S->R.h[i] = h;
+        S->R.fe[i] = fe;
+        S->R.w[i] = w;
+        S->R.kind[i] = (unsigned char)(kind < 0 ? MRZ_DK_NONE : kind);
+        S->R.h2[i] = h2;
+        S->R.w2[i] = w2;
+        S->R.kind2[i] = (unsigned char)kind2;
+        S->R.occ_t[i] = occ_t;
+        S->R.occ_off[i] = occ_off;
+        S->R.old_t[i] = old_t;
+        S->R.old_t2[i] = old_t2;
+        S->R.nsame[i] = (unsigned char)ns;
+        S->R.flags[i] = (unsigned char)((ins ? MRZ_DF_INS : 0) | (cplx ? MRZ_DF_CPLX : 0));
+        S->R.cp_scan[i] = clean_ptr;
+        S->R.xw_seen[i] = (unsigned short)xw_n;
+    }
+}
+
+// ---- scan helpers: more CUs for the SCAN phase ------------------------------------------------------------------------
+// The scan of a batch is read-only and most of what the engine costs at long runs (62 % of the kernel on the 64 GiB tar,
+// at 26 GB/s of table bytes: one CU's worth of loads in flight).  Up to MRZ_DEEP_SCANNERS more workgroups of the grid --
+// blocks xcd + 8, xcd + 16, ...: the committer's XCD under round-robin placement, CHECKED at run time (HW_REG_XCC_ID),
+// because they read the table through that XCD's L2 -- take a share of every batch's lanes: the committer posts the batch
+// (positions, tags, masks) in device memory, every helper scans the lanes dealt to it into its own LDS and copies the
+// records out; the committer scans its own share meanwhile, waits for the helpers' lanes and copies their records in.
+// Rescans, conflicts and the commit stay the committer's.  A helper that is not there (not resident, another XCD, a
+// launch without spare blocks) is simply not dealt any lanes: helpers check in with a ticket and the committer counts
+// who has.  All spins are bounded or end with the launch (quit).
+#ifndef MRZ_DEEP_SCANNERS
+#define MRZ_DEEP_SCANNERS 7
+#endif
+#ifndef MRZ_DEEP_HELP_MIN
+#define MRZ_DEEP_HELP_MIN 48  // lanes a batch must have before it is dealt out
+#endif
+
+struct mrz_deep_shared {  // device memory, zeroed by the host before every launch
+    // polled control words (agent scope), one 128-byte line
+    unsigned long long seq;        // number of the batch posted last (0: none yet)
+    unsigned long long quit;       // the launch is over
+    unsigned long long n_ok;       // helpers that have checked in (tickets handed out)
+    unsigned long long xcc_plus1;  // the committer's XCC id + 1 (0: not yet posted)
+    unsigned long long pad0[12];
+    // the job of batch `seq`, one line
+    long long nb, nscan, better, tag_mask, clean_ptr, xw_n;
+    long long pad1[10];
+    // lanes the helpers have finished for batch `seq`, its own line
+    unsigned long long done;
+    unsigned long long pad2[15];
+    mrz_deep_recs R;  // q / t of every lane (committer), everything else of the helpers' lanes (helpers)
+};
+
+#ifdef __HIP_DEVICE_COMPILE__
+#define MRZ_DEEP_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define MRZ_DEEP_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define MRZ_DEEP_XCC_ID() (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15)
+#else
+#define MRZ_DEEP_ACQUIRE() ((void)0)
+#define MRZ_DEEP_RELEASE() ((void)0)
+#define MRZ_DEEP_XCC_ID() 0
+#endif
+
+// copies the scan record of lane i (everything but q / t) from `src` to `dst`; called by the lane's own thread
+__device__ __forceinline__ void mrz_deep_rec_copy(mrz_deep_recs *dst, const mrz_deep_recs *src, int i) {
+    dst->occ_t[i] = src->occ_t[i];
+    dst->occ_off[i] = src->occ_off[i];
+    dst->old_t[i] = src->old_t[i];
+    dst->old_t2[i] = src->old_t2[i];
+    dst->cp_scan[i] = src->cp_scan[i];
+    dst->h[i] = src->h[i];
+    dst->fe[i] = src->fe[i];
+    dst->w[i] = src->w[i];
+    dst->h2[i] = src->h2[i];
+    dst->w2[i] = src->w2[i];
+    dst->xw_seen[i] = src->xw_seen[i];
+    dst->kind[i] = src->kind[i];
+    dst->kind2[i] = src->kind2[i];
+    dst->flags[i] = src->flags[i];
+    const int ns = src->nsame[i];
+    dst->nsame[i] = (unsigned char)ns;
+    for (int k = 0; k < ns; k++) {
+        dst->same_slot[i][k] = src->same_slot[i][k];
+        dst->same_off[i][k] = src->same_off[i][k];
+        dst->raw[i][k] = src->raw[i][k];
+    }
+}
+
+__device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, int64_t better, int64_t tag_mask,
+                                     int64_t clean_ptr, int xw_n, int lane);
+
+// a scan helper workgroup: see above
+__device__ static void mrz_deep_scan_helper(const mrz_cfg &C, mrz_deep_lds *S, mrz_deep_shared *G, int tid, int lane, int wave) {
+    // check in: on the committer's XCD?
+    if (tid == 0) {
+        long long spins = 0;
+        unsigned long long x = 0;
+        while ((x = __hip_atomic_load(&G->xcc_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 &&
+               !__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && spins++ < (1ll << 24))
+            __builtin_amdgcn_s_sleep(8);
+        int ticket = -1;
+        if (x != 0 && (int)x - 1 == (int)MRZ_DEEP_XCC_ID())
+            ticket = (int)__hip_atomic_fetch_add(&G->n_ok, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S->ctl[0] = ticket;
+    }
+    __syncthreads();
+    const int ticket = mrz_uni(S->ctl[0]);
+    if (ticket < 0 || ticket >= MRZ_DEEP_SCANNERS) return;
+    const int me = ticket + 1;  // my share: lanes i with i % nscan == me
+    unsigned long long seen = 0;
+    while (true) {
+        if (tid == 0) {
+            long long spins = 0;
+            unsigned long long sq = 0;
+            int v = 1;
+            while (true) {
+                sq = __hip_atomic_load(&G->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sq != seen) break;
+                if (__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins++ > MRZ_HELPER_SPIN_LIMIT) {
+                    v = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            MRZ_DEEP_ACQUIRE();  // nothing of the job, nor of the table, is served from this CU's L1 from before
+            S->ctl[1] = v;
+            S->lead.p = (int64_t)sq;
+        }
+        __syncthreads();
+        if (!mrz_uni(S->ctl[1])) return;
+        seen = (unsigned long long)mrz_uni64(S->lead.p);
+        const int nb = (int)G->nb, nscan = (int)G->nscan, xw_n = (int)G->xw_n;
+        const int64_t better = G->better, tag_mask = G->tag_mask, clean_ptr = G->clean_ptr;
+        int mine_n = 0;
+        if (me < nscan) {
+            for (int i = me + tid * nscan; i < nb; i += nscan * MRZ_DEEP_THREADS) {
+                S->R.q[i] = G->R.q[i];
+                S->R.t[i] = G->R.t[i];
+            }
+            __syncthreads();
+            int k = 0;
+            for (int i = me; i < nb; i += nscan, k++)
+                if (k % MRZ_DEEP_WAVES == wave) mrz_deep_scan(C, S, i, better, tag_mask, clean_ptr, xw_n, lane);
+            mine_n = k;
+            __syncthreads();
+            for (int i = me + tid * nscan; i < nb; i += nscan * MRZ_DEEP_THREADS) mrz_deep_rec_copy(&G->R, &S->R, i);
+            MRZ_DEEP_WAIT();
+        }
+        __syncthreads();
+        if (tid == 0 && mine_n) {
+            MRZ_DEEP_RELEASE();
+            __hip_atomic_fetch_add(&G->done, (unsigned long long)mine_n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -394,14 +535,14 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
 __device__ static bool mrz_deep_candidate_rec(const mrz_cfg &C, mrz_lead &L, mrz_deep_lds *S, int i, int *xw_n, int lane,
                                               int64_t *stat) {
     mrz_coop_lds *B = &S->coop;
-    const int64_t q = mrz_uni64(S->q[i]), t = mrz_uni64(S->t[i]);
-    const int ns = mrz_uni((int)S->nsame[i]);
-    const int f = mrz_uni((int)S->flags[i]);
+    const int64_t q = mrz_uni64(S->R.q[i]), t = mrz_uni64(S->R.t[i]);
+    const int ns = mrz_uni((int)S->R.nsame[i]);
+    const int f = mrz_uni((int)S->R.flags[i]);
     int64_t mlen = 0, m_off = 0, m_rev = 0;
     L.p = q;
     if (ns) {
         if (lane < ns) {
-            const int64_t op = S->same_off[i][lane];
+            const int64_t op = S->R.same_off[i][lane];
             B->same_off[lane] = op;
             int64_t ml, rv;
             bool lng;
@@ -416,23 +557,23 @@ __device__ static bool mrz_deep_candidate_rec(const mrz_cfg &C, mrz_lead &L, mrz
     }
     int nx = *xw_n;
     if (f & MRZ_DF_INS) {
-        const int kind = mrz_uni((int)S->kind[i]);
+        const int kind = mrz_uni((int)S->R.kind[i]);
         L.inserts++;
         L.count++;
-        int ws = mrz_uni(S->w[i]);
+        int ws = mrz_uni(S->R.w[i]);
         if (kind == MRZ_DK_OVER)
             L.count--;
         else if (kind == MRZ_DK_EVICT) {
             L.count--;
-            ws = mrz_uni(S->same_slot[i][(int)L.victim_round]);
+            ws = mrz_uni(S->R.same_slot[i][(int)L.victim_round]);
             L.victim_round = L.victim_round + 1 == C.max_chain ? 0 : L.victim_round + 1;
         } else if (kind == MRZ_DK_DISPLACE) {
-            const int w2 = mrz_uni(S->w2[i]);
-            if (mrz_uni((int)S->kind2[i]) == MRZ_DK_OVER) L.count--;
+            const int w2 = mrz_uni(S->R.w2[i]);
+            if (mrz_uni((int)S->R.kind2[i]) == MRZ_DK_OVER) L.count--;
             if (lane == 0) {
                 mrz_slot oc;
-                oc.off = S->occ_off[i];
-                oc.t = S->occ_t[i];
+                oc.off = S->R.occ_off[i];
+                oc.t = S->R.occ_t[i];
                 C.tab[w2] = oc;
                 S->xw_slot[nx] = w2;
             }
@@ -485,10 +626,11 @@ __device__ __forceinline__ int mrz_deep_first(bool flag, int *wm, int lane, int 
     return r;
 }
 
-__global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_args a) {
+__global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_args a, mrz_deep_shared *G, int scanners) {
 #ifdef MRZ_EMU_LDS_PER_BLOCK
-    static mrz_deep_lds deep_one;
-    mrz_deep_lds *S = &deep_one;
+    // (the CPU emulator of the test suite keeps `__shared__` in one static copy: one per workgroup that has a role here)
+    static mrz_deep_lds deep_all[1 + MRZ_DEEP_SCANNERS];
+    mrz_deep_lds *S = &deep_all[(blockIdx.x / 8) % (1 + MRZ_DEEP_SCANNERS)];
 #else
     __shared__ mrz_deep_lds deep;
     mrz_deep_lds *S = &deep;
@@ -499,14 +641,16 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
     mrz_seq_state *st = a.st;
     if (st->finished || st->error) return;
     const int xcd = a.xcd & 7;
-    const bool is_seq = (int)blockIdx.x == xcd;
+    const int bx = (int)blockIdx.x;
+    const bool is_seq = bx == xcd;
+    const bool is_scanner = G != nullptr && !is_seq && bx % 8 == xcd && bx / 8 >= 1 && bx / 8 <= scanners && bx / 8 <= MRZ_DEEP_SCANNERS;
 #if MRZ_HELPER_WGS > 0
-    if (!is_seq) {
+    if (!is_seq && !is_scanner) {
         if (a.gmailbox) mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
         return;
     }
 #else
-    if (!is_seq) return;
+    if (!is_seq && !is_scanner) return;
 #endif
     mrz_cfg C;
     C.buf = a.buf;
@@ -538,12 +682,19 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
     K.seg_start = st->seg_start;
     K.seg_end = st->seg_end;
     K.n = st->n_cand;
+    if (is_scanner) {
+        mrz_deep_scan_helper(C, S, G, tid, lane, wave);
+        return;
+    }
     if (K.seg_end <= K.seg_start) {
+        if (tid == 0 && G) __hip_atomic_store(&G->quit, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if MRZ_HELPER_WGS > 0
         if (tid == 0 && C.gmb) mrz_g_storeu(&C.gmb->quit, 1ull);
 #endif
         return;
     }
+    if (tid == 0 && G) __hip_atomic_store(&G->xcc_plus1, (unsigned long long)MRZ_DEEP_XCC_ID() + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long batch_seq = 0;
     const int64_t lim = (C.end < K.seg_end - 1) ? C.end : K.seg_end - 1;  // last candidate position of this launch
     const int smask = (int)C.slot_mask;
     const int max_chain = (int)C.max_chain;
@@ -605,8 +756,8 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
         const int incl = mrz_deep_incl(live ? 1 : 0, S->wsum, lane, wave, &total);
         const int at = incl - 1;
         if (live && at < MRZ_DEEP_LANES) {
-            S->q[at] = my_q;
-            S->t[at] = my_t;
+            S->R.q[at] = my_q;
+            S->R.t[at] = my_t;
             S->idx[at] = (int)(ci + tid);
         }
         const int nb = total < MRZ_DEEP_LANES ? total : MRZ_DEEP_LANES;
@@ -623,8 +774,61 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
         ST_ADD(MRZ_ST_D_LANES, nb);
         PROF_ADD(MRZ_ST_D_T_FORM);
         // ---- SCAN --------------------------------------------------------------------------------------------------
-        if (!loose)
-            for (int i = wave; i < nb; i += MRZ_DEEP_WAVES) mrz_deep_scan(C, S, i, better, L.tag_mask, L.clean_ptr, 0, lane);
+        if (!loose) {
+            // how many workgroups scan this batch: the helpers that have checked in take lanes i with i % nscan != 0
+            int nscan = 1;
+            if (G && nb >= MRZ_DEEP_HELP_MIN) {
+                int nh = (int)mrz_uni64((int64_t)__hip_atomic_load(&G->n_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (nh > MRZ_DEEP_SCANNERS) nh = MRZ_DEEP_SCANNERS;
+                if (nh > scanners) nh = scanners;
+                nscan = 1 + nh;
+            }
+            int helper_lanes = 0;
+            if (nscan > 1) {
+                if (tid < nb) {
+                    G->R.q[tid] = S->R.q[tid];
+                    G->R.t[tid] = S->R.t[tid];
+                }
+                if (tid == 0) {
+                    G->nb = nb;
+                    G->nscan = nscan;
+                    G->better = better;
+                    G->tag_mask = L.tag_mask;
+                    G->clean_ptr = L.clean_ptr;
+                    G->xw_n = 0;
+                    __hip_atomic_store(&G->done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                MRZ_DEEP_WAIT();  // every thread's job stores (and, before them, the table stores of the last commit)
+                __syncthreads();
+                batch_seq++;
+                if (tid == 0) {
+                    MRZ_DEEP_RELEASE();
+                    __hip_atomic_store(&G->seq, batch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                helper_lanes = nb - (nb + nscan - 1) / nscan;
+            }
+            {
+                int k = 0;
+                for (int i = 0; i < nb; i += nscan, k++)
+                    if (k % MRZ_DEEP_WAVES == wave) mrz_deep_scan(C, S, i, better, L.tag_mask, L.clean_ptr, 0, lane);
+            }
+            if (nscan > 1) {
+                if (tid == 0) {
+                    long long spins = 0;
+                    while (__hip_atomic_load(&G->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)helper_lanes &&
+                           spins++ < (1ll << 26))
+                        __builtin_amdgcn_s_sleep(1);
+                    S->ctl[6] = spins < (1ll << 26) ? 1 : 0;
+                    MRZ_DEEP_ACQUIRE();  // the helpers' records are not served from lines this CU's L1 held before
+                }
+                __syncthreads();
+                if (!mrz_uni(S->ctl[6])) {  // cannot happen: a helper that has checked in answers
+                    if (tid == 0) C.st->error = 7;
+                    ok = false;
+                } else if (tid < nb && tid % nscan != 0)
+                    mrz_deep_rec_copy(&S->R, &G->R, tid);
+            }
+        }
         __syncthreads();
         PROF_ADD(MRZ_ST_D_T_SCAN);
         // ---- COMMIT: rounds ------------------------------------------------------------------------------------------
@@ -650,23 +854,23 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     S->tmap_lane[k] = 0x7fffffff;
                 }
                 __syncthreads();
-                const int f = mine ? S->flags[i] : 0;
+                const int f = mine ? S->R.flags[i] : 0;
                 const bool ins = mine && (f & MRZ_DF_INS), cplx = mine && (f & MRZ_DF_CPLX);
-                const int kind = mine ? S->kind[i] : MRZ_DK_NONE, kind2 = mine ? S->kind2[i] : MRZ_DK_NONE;
-                const int64_t q = mine ? S->q[i] : 0, t = mine ? S->t[i] : 0;
-                const int w = mine ? S->w[i] : -1, w2 = mine ? S->w2[i] : -1, fe = mine ? S->fe[i] : -1;
-                const int h = mine ? S->h[i] : 0, h2 = mine ? S->h2[i] : 0;
-                const int64_t occ_t = mine ? S->occ_t[i] : 0;
+                const int kind = mine ? S->R.kind[i] : MRZ_DK_NONE, kind2 = mine ? S->R.kind2[i] : MRZ_DK_NONE;
+                const int64_t q = mine ? S->R.q[i] : 0, t = mine ? S->R.t[i] : 0;
+                const int w = mine ? S->R.w[i] : -1, w2 = mine ? S->R.w2[i] : -1, fe = mine ? S->R.fe[i] : -1;
+                const int h = mine ? S->R.h[i] : 0, h2 = mine ? S->R.h2[i] : 0;
+                const int64_t occ_t = mine ? S->R.occ_t[i] : 0;
                 const bool wr_w = ins && !cplx && (kind == MRZ_DK_EMPTY || kind == MRZ_DK_OVER || kind == MRZ_DK_DISPLACE);
                 const bool wr_w2 = ins && !cplx && kind == MRZ_DK_DISPLACE;
                 if (ins && !cplx) {
                     if (wr_w) mrz_deep_smap_put(S, w, i);
                     if (wr_w2) mrz_deep_smap_put(S, w2, i);
                     mrz_deep_tmap_put(S, t, i);
-                    if (kind == MRZ_DK_OVER) mrz_deep_tmap_put(S, S->old_t[i], i);
+                    if (kind == MRZ_DK_OVER) mrz_deep_tmap_put(S, S->R.old_t[i], i);
                     if (kind == MRZ_DK_DISPLACE) {
                         mrz_deep_tmap_put(S, occ_t, i);
-                        if (kind2 == MRZ_DK_OVER) mrz_deep_tmap_put(S, S->old_t2[i], i);
+                        if (kind2 == MRZ_DK_OVER) mrz_deep_tmap_put(S, S->R.old_t2[i], i);
                     }
                 }
                 __syncthreads();
@@ -696,21 +900,21 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         }
                         if (cmin < i || (f & MRZ_DF_STALE)) stop |= MRZ_DS_CONFLICT;
                         // a real match (or a compare beyond the 64-byte reach) among the tag-equal entries
-                        const int ns = S->nsame[i];
+                        const int ns = S->R.nsame[i];
                         const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
                         for (int k = 0; k < ns; k++)
-                            if (mrz_deep_pair_eval(S->raw[i][k], q, S->same_off[i][k], floor_p)) stop |= MRZ_DS_COOP;
+                            if (mrz_deep_pair_eval(S->R.raw[i][k], q, S->R.same_off[i][k], floor_p)) stop |= MRZ_DS_COOP;
                         // a store that takes a failing entry out of the sweep's way changes which entries later culls find
                         if (wr_w && kind == MRZ_DK_OVER && w >= cw_base && w < cw_base + cw_len) stop |= MRZ_DS_COOP;
                         if (wr_w2 && kind2 == MRZ_DK_OVER && w2 >= cw_base && w2 < cw_base + cw_len) stop |= MRZ_DS_COOP;
                         // a slot the cooperative path has written since the scan, inside what the lane has read
-                        for (int k = S->xw_seen[i]; k < xw_n; k++) {
+                        for (int k = S->R.xw_seen[i]; k < xw_n; k++) {
                             const int xs = S->xw_slot[k];
                             if ((((xs - h) & smask) <= ((fe - h) & smask)) || (wr_w2 && (((xs - h2) & smask) <= ((w2 - h2) & smask))))
                                 stop |= MRZ_DS_CULLED;
                         }
                         // culled since the scan (by earlier rounds / batches)?
-                        const int64_t cp0 = S->cp_scan[i];
+                        const int64_t cp0 = S->R.cp_scan[i];
                         if (L.clean_ptr != cp0) {
                             const int lc = (int)(L.clean_ptr - cp0) + 1;
                             if (mrz_deep_ranges_meet(h, ((fe - h) & smask) + 1, (int)cp0, lc, smask)) stop |= MRZ_DS_CULLED;
@@ -755,7 +959,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 int64_t c_before = L.count + ((i1 & 1023) - d);
                 if (c_before > C.limit) c_before = C.limit;
                 const bool cull = a_ins && (c_before + d > C.limit);
-                const int i2 = mrz_deep_incl((cull ? 1 : 0) | ((inb ? (int)S->nsame[i] : 0) << 10), S->wsum2, lane, wave, &dummy);
+                const int i2 = mrz_deep_incl((cull ? 1 : 0) | ((inb ? (int)S->R.nsame[i] : 0) << 10), S->wsum2, lane, wave, &dummy);
                 int cslot = -1;
                 const int r_before = (i2 & 1023) - (cull ? 1 : 0);  // culls of the lanes before this one
                 if (cull) {
@@ -779,11 +983,11 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 if (mine && i == e2) S->ctl[4] = stop;
                 // a lane behind the committed ones that depends on what one of them has written stays marked until it has
                 // been scanned again (the round may end in the cooperative path, and the next one only knows ITS lanes' plans)
-                if (mine && i >= e2 && cmin < e2) S->flags[i] = (unsigned char)(f | MRZ_DF_STALE);
+                if (mine && i >= e2 && cmin < e2) S->R.flags[i] = (unsigned char)(f | MRZ_DF_STALE);
                 // R6: lanes [next, e2) commit as scanned (insert_hash + clean_one_from_hash, src/rzip.c:256-328,579-584)
 #ifdef MRZ_DEEP_TRACE
                 if (mine && i < e2 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
-                    printf("bulk q=%lld ins=%d kind=%d w=%d w2=%d cslot=%d nsame=%d lane=%d next=%d e2=%d\n", (long long)q, (int)a_ins, kind, w, w2, cslot, (int)S->nsame[i], i, next, e2);
+                    printf("bulk q=%lld ins=%d kind=%d w=%d w2=%d cslot=%d nsame=%d lane=%d next=%d e2=%d\n", (long long)q, (int)a_ins, kind, w, w2, cslot, (int)S->R.nsame[i], i, next, e2);
 #endif
                 if (mine && i < e2) {
                     if (a_ins) {
@@ -791,11 +995,11 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         if (a_ev) {
                             const int er = ((i1 >> 10) & 1023) - 1;
                             const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
-                            ws = S->same_slot[i][vr];
+                            ws = S->R.same_slot[i][vr];
                         }
                         if (kind == MRZ_DK_DISPLACE) {
                             mrz_slot oc;
-                            oc.off = S->occ_off[i];
+                            oc.off = S->R.occ_off[i];
                             oc.t = occ_t;
                             C.tab[w2] = oc;
                         }
@@ -847,48 +1051,48 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     const int sf = mrz_uni(S->ctl[4]);
                     // (a lane that stops the round for the cooperative path AND whose scan no longer holds is scanned again
                     // first: its record then serves the replay)
-                    bool stop_stale = (sf & (MRZ_DS_CONFLICT | MRZ_DS_CULLED)) != 0 || (S->flags[next] & MRZ_DF_STALE);
-                    if (!stop_stale && !(S->flags[next] & MRZ_DF_CPLX)) {
-                        const int64_t cp0 = S->cp_scan[next];
+                    bool stop_stale = (sf & (MRZ_DS_CONFLICT | MRZ_DS_CULLED)) != 0 || (S->R.flags[next] & MRZ_DF_STALE);
+                    if (!stop_stale && !(S->R.flags[next] & MRZ_DF_CPLX)) {
+                        const int64_t cp0 = S->R.cp_scan[next];
                         if (L.clean_ptr != cp0) {  // culled by the lanes that have just committed?
                             const int lc = (int)(L.clean_ptr - cp0) + 1;
-                            const int hh = S->h[next], ff = S->fe[next];
+                            const int hh = S->R.h[next], ff = S->R.fe[next];
                             stop_stale = mrz_deep_ranges_meet(hh, ((ff - hh) & smask) + 1, (int)cp0, lc, smask);
-                            if (!stop_stale && (S->flags[next] & MRZ_DF_INS) && S->kind[next] == MRZ_DK_DISPLACE) {
-                                const int hh2 = S->h2[next], ww2 = S->w2[next];
+                            if (!stop_stale && (S->R.flags[next] & MRZ_DF_INS) && S->R.kind[next] == MRZ_DK_DISPLACE) {
+                                const int hh2 = S->R.h2[next], ww2 = S->R.w2[next];
                                 stop_stale = mrz_deep_ranges_meet(hh2, ((ww2 - hh2) & smask) + 1, (int)cp0, lc, smask);
                             }
                         }
                     }
                     if ((sf & MRZ_DS_COOP) && !stop_stale) {
                         coop_lane = next;
-                        use_record = !(S->flags[next] & MRZ_DF_CPLX);
+                        use_record = !(S->R.flags[next] & MRZ_DF_CPLX);
                     } else if ((sf & MRZ_DS_NOCULL) && next == round_start && !stop_stale) {
                         coop_lane = next;  // (the sweep has to go further than the window reaches, or to wrap: the generic step)
-                        use_record = !(S->flags[next] & MRZ_DF_CPLX);
+                        use_record = !(S->R.flags[next] & MRZ_DF_CPLX);
                     } else {
                         // lanes at or behind `next` whose scan no longer holds -- an earlier lane that HAS committed touched
                         // what they depend on, or the sweep has reached into what they read -- are scanned again, all at
                         // once, against the table as it is now
                         bool again = false;
-                        if (i >= next && i < nb && !(S->flags[i] & MRZ_DF_CPLX)) {
-                            again = (S->flags[i] & MRZ_DF_STALE) != 0;
+                        if (i >= next && i < nb && !(S->R.flags[i] & MRZ_DF_CPLX)) {
+                            again = (S->R.flags[i] & MRZ_DF_STALE) != 0;
                             {
-                                const int hh = S->h[i], ff = S->fe[i], hh2 = S->h2[i], ww2 = S->w2[i];
-                                const bool dsp = (S->flags[i] & MRZ_DF_INS) && S->kind[i] == MRZ_DK_DISPLACE;
-                                for (int k = S->xw_seen[i]; k < xw_n && !again; k++) {
+                                const int hh = S->R.h[i], ff = S->R.fe[i], hh2 = S->R.h2[i], ww2 = S->R.w2[i];
+                                const bool dsp = (S->R.flags[i] & MRZ_DF_INS) && S->R.kind[i] == MRZ_DK_DISPLACE;
+                                for (int k = S->R.xw_seen[i]; k < xw_n && !again; k++) {
                                     const int xs = S->xw_slot[k];
                                     again = (((xs - hh) & smask) <= ((ff - hh) & smask)) || (dsp && (((xs - hh2) & smask) <= ((ww2 - hh2) & smask)));
                                 }
                             }
                             if (!again) {
-                                const int64_t cp0 = S->cp_scan[i];
+                                const int64_t cp0 = S->R.cp_scan[i];
                                 if (L.clean_ptr != cp0) {
                                     const int lc = (int)(L.clean_ptr - cp0) + 1;
-                                    const int hh = S->h[i], ff = S->fe[i];
+                                    const int hh = S->R.h[i], ff = S->R.fe[i];
                                     again = mrz_deep_ranges_meet(hh, ((ff - hh) & smask) + 1, (int)cp0, lc, smask);
-                                    if (!again && (S->flags[i] & MRZ_DF_INS) && S->kind[i] == MRZ_DK_DISPLACE) {
-                                        const int hh2 = S->h2[i], ww2 = S->w2[i];
+                                    if (!again && (S->R.flags[i] & MRZ_DF_INS) && S->R.kind[i] == MRZ_DK_DISPLACE) {
+                                        const int hh2 = S->R.h2[i], ww2 = S->R.w2[i];
                                         again = mrz_deep_ranges_meet(hh2, ((ww2 - hh2) & smask) + 1, (int)cp0, lc, smask);
                                     }
                                 }
@@ -913,7 +1117,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 // stores (the insert's write-back list, the cull) go on the list of slots the lanes behind it have to check
                 // their scans against; a match it emits carries the matcher over the lanes it covers.
                 if (wave == 0) {
-                    const int64_t q = mrz_uni64(S->q[coop_lane]), t = mrz_uni64(S->t[coop_lane]);
+                    const int64_t q = mrz_uni64(S->R.q[coop_lane]), t = mrz_uni64(S->R.t[coop_lane]);
                     const int64_t mm0 = L.min_mask, tm0 = L.tag_mask;
                     L.p = q;
                     int nx_rec = xw_n;
@@ -958,7 +1162,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 // the first lane behind the matcher's position (an emitted match covers the lanes inside it)
                 {
                     const int i = tid;
-                    const int nf = mrz_deep_first(i > coop_lane && i < nb && S->q[i] > L.p, S->wmin3, lane, wave, tid, nb);
+                    const int nf = mrz_deep_first(i > coop_lane && i < nb && S->R.q[i] > L.p, S->wmin3, lane, wave, tid, nb);
                     next = nf;
                 }
                 PROF_ADD(MRZ_ST_D_T_RESCAN);
@@ -967,7 +1171,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
         // where the next batch begins: behind the entries this one has covered -- or, when the masks have moved or a match
         // has carried the matcher beyond them, at the first entry behind its position
         if (ok) {
-            if (cut || L.p > mrz_uni64(S->q[nb - 1])) {
+            if (cut || L.p > mrz_uni64(S->R.q[nb - 1])) {
                 int64_t pos = L.p + 1;
                 if (pos < K.seg_start) pos = K.seg_start;
                 ci = mrz_cand_lower_bound(K, pos, lane);
@@ -982,6 +1186,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
     stat[MRZ_ST_D_T_TOTAL] += (int64_t)__builtin_amdgcn_s_memtime() - launch_t0;
 #endif
     if (tid == 0) {
+        if (G) __hip_atomic_store(&G->quit, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if MRZ_HELPER_WGS > 0
         if (C.gmb) mrz_g_storeu(&C.gmb->quit, 1ull);
 #endif
@@ -1011,7 +1216,8 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
 
 extern "C" hipError_t mrz_launch_sequencer_deep(hipStream_t stream, const uint8_t *buf, mrz_slot *tab, const mrz_cand *cand,
                                                 const int *tile_off, const mrz_u64 *bitmap, mrz_event *events,
-                                                mrz_seq_state *st, void *gmailbox, int n_helpers, int xcd) {
+                                                mrz_seq_state *st, void *gmailbox, int n_helpers, int xcd, void *deep_shared,
+                                                int scanners) {
     mrz_seq_args a;
     a.buf = buf;
     a.tab = tab;
@@ -1033,8 +1239,27 @@ extern "C" hipError_t mrz_launch_sequencer_deep(hipStream_t stream, const uint8_
         hipError_t e = hipMemsetAsync(gmailbox, 0, sizeof(mrz_gmailbox), stream);
         if (e != hipSuccess) return e;
     }
+    if (scanners < 0 || !deep_shared) scanners = 0;
+    if (scanners > MRZ_DEEP_SCANNERS) scanners = MRZ_DEEP_SCANNERS;
     unsigned grid = (unsigned)(1 + a.n_helpers);
     if (grid < (unsigned)(a.xcd + 1)) grid = (unsigned)(a.xcd + 1);
-    hipLaunchKernelGGL(mrz_seq_deep_kernel, dim3(grid), dim3(MRZ_DEEP_THREADS), 0, stream, a);
+#ifdef MRZ_EMU_LDS_PER_BLOCK
+    // (test emulator: no farm, but room for the scan helpers -- blocks xcd + 8, xcd + 16, ...; they only run beside the
+    // committer in the emulator's co-resident mode, and exit at once otherwise)
+    if (scanners > 0) {
+        grid = (unsigned)(8 * scanners + a.xcd + 1);
+        emu::request_coresident();
+    }
+#else
+    while (scanners > 0 && grid < (unsigned)(8 * scanners + a.xcd + 1)) scanners--;  // (blocks there are)
+#endif
+    if (deep_shared) {
+        hipError_t e = hipMemsetAsync(deep_shared, 0, offsetof(mrz_deep_shared, R), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(mrz_seq_deep_kernel, dim3(grid), dim3(MRZ_DEEP_THREADS), 0, stream, a, (mrz_deep_shared *)deep_shared,
+                       scanners);
     return hipGetLastError();
 }
+
+extern "C" size_t mrz_seq_deep_shared_size(void) { return sizeof(mrz_deep_shared); }
