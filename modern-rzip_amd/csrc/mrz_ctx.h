@@ -63,7 +63,7 @@ struct mrz_ctx {
     unsigned *d_wlog;    // its write log: one batch stamp per few table slots
     int seq_wgs;         // sequencer workgroups per wide launch (MRZ_SEQ_WGS in the environment; default 3)
     void *d_deep_shared; // what the deep engine's committer and its scan helpers hand to each other (mrz_seq_deep.hip)
-    int deep_scanners;   // scan helper workgroups per deep launch (MRZ_DEEP_SCANNERS; default 7)
+    int deep_scanners;   // scan helper workgroups per deep launch (MRZ_DEEP_SCANNERS; default 15)
     int farm_helpers;  // helper workgroups per sequencer launch; -1 = farm_default
     int farm_default;  // the default for this ctx's device (about one per CU), fixed in mrz_open
     void *d_rs_tables;  // Reed-Solomon tables (mrz_rs.hip)

@@ -40,7 +40,7 @@
 //
 // Bound: table bytes scanned (cache / fabric bandwidth of the sequencer's CU) and wave 0's serial commit; DESIGN.md 4.2.
 #ifndef MRZ_DEEP_WAVES
-#define MRZ_DEEP_WAVES 16
+#define MRZ_DEEP_WAVES 8
 #endif
 #define MRZ_SEQ_WAVES MRZ_DEEP_WAVES
 #include "mrz_seq_common.h"
@@ -401,7 +401,7 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
 // launch without spare blocks) is simply not dealt any lanes: helpers check in with a ticket and the committer counts
 // who has.  All spins are bounded or end with the launch (quit).
 #ifndef MRZ_DEEP_SCANNERS
-#define MRZ_DEEP_SCANNERS 7
+#define MRZ_DEEP_SCANNERS 15
 #endif
 #ifndef MRZ_DEEP_HELP_MIN
 #define MRZ_DEEP_HELP_MIN 48  // lanes a batch must have before it is dealt out
@@ -526,13 +526,19 @@ __device__ static void mrz_deep_scan_helper(const mrz_cfg &C, mrz_deep_lds *S, m
     }
 }
 
+// (out of line: the cooperative path is large and rare -- inlined, twice, it cost the scan loop 120 spilled registers)
+__device__ static __attribute__((noinline)) bool mrz_deep_coop(const mrz_cfg &C, mrz_lead &L, mrz_coop_lds *B, int64_t t,
+                                                               int lane, int64_t *stat) {
+    return mrz_seq_candidate(C, L, B, t, lane, stat);
+}
+
 // One candidate whose scan still holds, replayed by wave 0 FROM ITS RECORD instead of walking the table again: the
 // tag-equal entries are measured exactly (64-byte probes per lane, long ones by the striped path / the compare farm:
 // mrz_resolve_entries) and folded in probe order (find_best_match, src/rzip.c:443-454), the insert lands where the scan
 // found its place (insert_hash :256-301), the cull is the generic sweep step (:305-328), then the lazy selection and the
 // emit rule (:586-599).  For lanes with a real match among their entries -- the table walk of the cooperative path is
 // what costs at long runs.  Appends the slots it writes to S->xw_slot[*xw_n ...]; false on event-list overflow.
-__device__ static bool mrz_deep_candidate_rec(const mrz_cfg &C, mrz_lead &L, mrz_deep_lds *S, int i, int *xw_n, int lane,
+__device__ static __attribute__((noinline)) bool mrz_deep_candidate_rec(const mrz_cfg &C, mrz_lead &L, mrz_deep_lds *S, int i, int *xw_n, int lane,
                                               int64_t *stat) {
     mrz_coop_lds *B = &S->coop;
     const int64_t q = mrz_uni64(S->R.q[i]), t = mrz_uni64(S->R.t[i]);
@@ -1117,37 +1123,49 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 // stores (the insert's write-back list, the cull) go on the list of slots the lanes behind it have to check
                 // their scans against; a match it emits carries the matcher over the lanes it covers.
                 if (wave == 0) {
-                    const int64_t q = mrz_uni64(S->R.q[coop_lane]), t = mrz_uni64(S->R.t[coop_lane]);
-                    const int64_t mm0 = L.min_mask, tm0 = L.tag_mask;
-                    L.p = q;
-                    int nx_rec = xw_n;
-                    const bool rec = use_record && xw_n + 4 <= MRZ_DEEP_XW;
-                    const bool okc = rec ? mrz_deep_candidate_rec(C, L, S, coop_lane, &nx_rec, lane, stat)
-                                         : mrz_seq_candidate(C, L, &S->coop, t, lane, stat);
+                    int cl = coop_lane;
+                    int verdict = 1, nx = xw_n;
+                    // (before the first cull no lane has a scan to keep valid: wave 0 goes on through the batch by itself, one
+                    // candidate after the other, for as long as nothing else changes -- the same call, in a loop)
+                    while (true) {
+                        const int64_t q = mrz_uni64(S->R.q[cl]), t = mrz_uni64(S->R.t[cl]);
+                        const int64_t mm0 = L.min_mask, tm0 = L.tag_mask;
+                        L.p = q;
+                        int nx_rec = nx;
+                        const bool rec = use_record && nx + 4 <= MRZ_DEEP_XW;
+                        const bool okc = rec ? mrz_deep_candidate_rec(C, L, S, cl, &nx_rec, lane, stat)
+                                             : mrz_deep_coop(C, L, &S->coop, t, lane, stat);
+                        ST_ADD(MRZ_ST_D_COOP, 1);
 #ifdef MRZ_DEEP_TRACE
-                    if (lane == 0 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
-                        printf("coop q=%lld -> p=%lld ev=%lld cur_len=%lld nw=%d lane=%d\n", (long long)q, (long long)L.p, (long long)L.n_events, (long long)L.cur_len, S->coop.n_written, coop_lane);
+                        if (lane == 0 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
+                            printf("coop q=%lld -> p=%lld ev=%lld cur_len=%lld nw=%d lane=%d\n", (long long)q, (long long)L.p, (long long)L.n_events, (long long)L.cur_len, S->coop.n_written, cl);
 #endif
-                    const bool same_masks = L.min_mask == mm0 && L.tag_mask == tm0;
-                    int nx = xw_n;
-                    const int nwr = rec ? 0 : mrz_uni(S->coop.n_written);
-                    const int64_t cs = rec ? -1 : mrz_uni64(S->coop.cull_slot);
-                    const bool room = nx + nwr + 1 <= MRZ_DEEP_XW;
-                    if (rec)
-                        nx = nx_rec;
-                    else if (okc && same_masks && room && !loose) {
-                        if (lane < nwr) S->xw_slot[nx + lane] = (int)S->coop.pend_h[lane];
-                        nx += nwr;
-                        if (cs >= 0) {
-                            if (lane == 0) S->xw_slot[nx] = (int)cs;
-                            nx++;
+                        const bool same_masks = L.min_mask == mm0 && L.tag_mask == tm0;
+                        const int nwr = rec ? 0 : mrz_uni(S->coop.n_written);
+                        const int64_t cs = rec ? -1 : mrz_uni64(S->coop.cull_slot);
+                        const bool room = nx + nwr + 1 <= MRZ_DEEP_XW;
+                        if (rec)
+                            nx = nx_rec;
+                        else if (okc && same_masks && room && !loose) {
+                            if (lane < nwr) S->xw_slot[nx + lane] = (int)S->coop.pend_h[lane];
+                            nx += nwr;
+                            if (cs >= 0) {
+                                if (lane == 0) S->xw_slot[nx] = (int)cs;
+                                nx++;
+                            }
                         }
+                        // (a match that ends BEFORE the emitting position takes the loop's p back, src/rzip.c:596: the
+                        // candidates behind its end run again -- the batch is formed again from there)
+                        verdict = !okc ? 3 : ((same_masks && (room || loose) && L.p >= q) ? 1 : 2);
+                        if (!(loose && verdict == 1)) break;
+                        int j = cl + 1;
+                        while (j < nb && mrz_uni64(S->R.q[j]) <= L.p) j++;  // (inside a match emitted meanwhile)
+                        if (j >= nb) break;
+                        cl = j;
                     }
                     if (lane == 0) {
                         S->lead = L;
-                        // (a match that ends BEFORE the emitting position takes the loop's p back, src/rzip.c:596: the
-                        // candidates behind its end run again -- the batch is formed again from there)
-                        S->ctl[0] = !okc ? 3 : ((same_masks && (room || loose) && L.p >= q) ? 1 : 2);
+                        S->ctl[0] = verdict;
                         S->ctl[5] = nx;
                     }
                     MRZ_DEEP_WAIT();
@@ -1156,7 +1174,6 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 L = S->lead;
                 xw_n = mrz_uni(S->ctl[5]);
                 const int v = mrz_uni(S->ctl[0]);
-                ST_ADD(MRZ_ST_D_COOP, 1);
                 if (v == 3) ok = false;
                 if (v == 2) cut = true;
                 // the first lane behind the matcher's position (an emitted match covers the lanes inside it)

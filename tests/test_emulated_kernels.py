@@ -85,23 +85,42 @@ def test_sequencer_workgroups_take_turns(emu_lib, oracle, wgs, monkeypatch):
     _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 19, seed=4), level=1, table=True)
 
 
+def _deep_mix():
+    """Level-1 input (2 MiB table) that takes the deep engine through its states: noise until the table is full and the
+    culling has begun (before that no lane is scanned), then text (tag-equal entries, real matches: record replay and
+    cooperative path between bulk commits), a repeat of earlier noise (one long match, lanes dropped behind it) and
+    noise again."""
+    noise = _util.xorshift_noise(1700000, seed=3)
+    return noise + _util.zipf_text(420000, seed=4) + noise[300000:420000] + _util.xorshift_noise(150000, seed=8)
+
+
 def test_deep_engine_alone(emu_lib, oracle, monkeypatch):
-    """MRZ_SEQ_ENGINE=deep: every segment on the deep engine (run scans by all waves, in-order commit with the precise
-    staleness rule, stale lanes scanned again, cooperative path for real matches): before the first cull (no lane is
-    scanned), through culling and several mask promotions at level 1 (2 MiB table: long runs), noise, text, repeats,
-    evictions (many equal tags), duplicates with backward extension."""
+    """MRZ_SEQ_ENGINE=deep: every segment on the deep engine (run scans by all waves, conflicts from the lanes' planned
+    writes, bulk commit with prefix sums, stale lanes scanned again, record replay / cooperative path for real
+    matches); the whole table is compared too."""
     monkeypatch.setenv("MRZ_SEQ_ENGINE", "deep")
-    want = _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(3 << 20, seed=3), level=1, table=True)
-    assert want["min_mask"] > 15 and want["stats"]["inserts"] > want["hash_count"]
-    _parity.check_chunk(emu_lib, oracle, _util.tar_like(1 << 20, seed=4), level=1, table=True)
-    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(400000, seed=4), level=1, table=True)
-    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(160000, seed=4), table=True)
-    _parity.check_chunk(emu_lib, oracle, _util.xorshift_noise(100000, seed=3), table=True, victim_round=7)
-    _parity.check_chunk(emu_lib, oracle, _util.rep64k(24, seed=9, period=2048), victim_round=3)
+    want = _parity.check_chunk(emu_lib, oracle, _deep_mix(), level=1, table=True, victim_round=1)
+    assert want["stats"]["inserts"] > want["hash_count"] and want["stats"]["matches"] >= 2 and want["stats"]["tag_hits"] > 10
     _parity.check_chunk(emu_lib, oracle, _util.rep64k(40, seed=9, period=997), level=2, table=True)
     blk = _util.xorshift_noise(70000, seed=12)
     _parity.check_chunk(emu_lib, oracle, blk + blk + b"xyz" + blk[5:])
-    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(70000, seed=4), seg_positions=4096, cand_cap=4096)
+    _parity.check_chunk(emu_lib, oracle, _util.zipf_text(30000, seed=4), seg_positions=4096, cand_cap=4096)
+
+
+def test_deep_engine_with_scan_helpers(emu_lib, oracle, monkeypatch):
+    """The same with two scan helper workgroups beside the committer (the emulator runs them interleaved): batches are
+    dealt out through device memory, the helpers' records are copied back; and the per-segment choice (wide engine first,
+    ending its launch where the mask reaches MRZ_DEEP_MIN_BITS, then the deep engine)."""
+    monkeypatch.setenv("MRZ_EMU_CORESIDENT", "1")
+    monkeypatch.setenv("MRZ_DEEP_SCANNERS", "2")
+    monkeypatch.setenv("MRZ_DEEP_MIN_BITS", "5")
+    with m.RzipContext(level=1, max_chunk=4 << 20, lib=emu_lib) as ctx:
+        noise = _util.xorshift_noise(3300000, seed=3)
+        want = oracle.rzip_chunk(noise, level=1)
+        res, s0, s1 = ctx.rzip_chunk(noise)
+        assert (s0, s1) == (want["s0"], want["s1"]) and res.stats.as_dict() == want["stats"] and res.min_mask == 31
+        t = ctx.timings()
+        assert 1 <= t.n_deep < t.n_segments
 
 
 @pytest.mark.parametrize("engine", ["wide", "narrow"])

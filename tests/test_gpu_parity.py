@@ -485,6 +485,18 @@ def test_window_sharded_over_two_processes(gpu_lib):
     assert "window ok 268435456" in out
 
 
+def test_eight_matchers_on_eight_xcds(gpu_lib):
+    """Eight independent streams at once, one ctx each on its own XCD (mrz_set_xcd; own process: the HIP runtime has to
+    open enough hardware queues): every stream's result equals its solo run and the oracle."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_multictx.py"), "tar", "24", "8", "--check"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert last == {"oracle_equal": True, "all_identical": True}, r.stdout[-2000:]
+
+
 def test_c_caller_program(gpu_lib, tmp_path):
     """tests/c/capi_test.c: a plain C99 program (gcc, no ctypes) linked against libmrzgpu.so drives the chunk call and
     mrz_rzip_fd (file and pipe) and compares every byte with the oracle itself."""
