@@ -15,6 +15,16 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+
+// joins a thread when the scope is left, whichever way (an allocation that throws between the thread's start and its
+// join would otherwise destroy a joinable std::thread: std::terminate instead of MRZ_E_NOMEM at the C ABI)
+struct mrz_join_guard {
+    std::thread &t;
+    explicit mrz_join_guard(std::thread &th) : t(th) {}
+    ~mrz_join_guard() {
+        if (t.joinable()) t.join();
+    }
+};
 #include <vector>
 
 #include "../../include/mrzgpu_host.h"
@@ -406,6 +416,7 @@ int run_chunks(const mrz_control *ctl, Source &src, int stdin_mode, int64_t st_s
                 }
             }
             std::thread hasher([&]() { md5h.update(chunk.data(), (size_t)csz); });
+            mrz_join_guard hasher_guard(hasher);
             const int cb = mrz_chunk_bytes(csz);
             mrz_chunk_result res;
             rc = mrz_rzip_chunk(ctx, chunk.data(), csz, MRZ_MEM_HOST, cb, &victim_round, &res);
@@ -705,6 +716,7 @@ static int rzip_pipeline_impl(const mrz_control *ctl, const uint8_t *in, int64_t
         h.update(in, (size_t)n);
         h.finish(md5);
     });
+    mrz_join_guard hasher_guard(hasher);
 
     // consumer: the LZ4 gate (on its own ctx / stream) and the caller's function, block by block, in flush order
     std::mutex mu;
@@ -745,6 +757,21 @@ static int rzip_pipeline_impl(const mrz_control *ctl, const uint8_t *in, int64_t
             delete b;
         }
     });
+    // (the same for the consumer, which first has to be told that nothing more is coming)
+    struct consumer_guard_t {
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &done;
+        std::thread &t;
+        ~consumer_guard_t() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done = true;
+            }
+            cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    } consumer_guard{ mu, cv, producer_done, consumer };
 
     mrz_ctx *ctx = nullptr;
     if (!rc) rc = mrz_open(&ctx, ctl->device, ctl->rzip_compression_level, max_chunk < n ? max_chunk : n);
