@@ -276,6 +276,19 @@ def main():
         }
         if verify:
             out["verify"] = verify
+        if args.workload == "tar" and world == 1 and not args.no_verify:
+            # configs[2] is "GPU rzip + LZ4 test -> host back-end": the LZ4 compressibility gate (lz4_compresses,
+            # src/stream.c:1685-1733) over the blocks the two streams of this chunk would be flushed in (128 MiB stream buffers
+            # at -L7, src/stream.c:907-912), on the device, untimed -- what the gate adds to a step
+            blk = 128 << 20
+            blocks = [(res.d_s1 + a, min(blk, res.s1_len - a)) for a in range(0, res.s1_len, blk)]
+            blocks += [(res.d_s0 + a, min(blk, res.s0_len - a)) for a in range(0, res.s0_len, blk)]
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            verdicts = ctx.lz4_compresses(blocks, threshold=100)
+            gdt = time.perf_counter() - g0
+            out["lz4_gate"] = {"blocks": len(blocks), "seconds": round(gdt, 3), "skip_backend": sum(1 for v in verdicts if v == 0),
+                               "note": "mrz_lz4_compresses_batch over the stream blocks of the last step, device-resident, untimed"}
         if world == 1 and args.gib > 4.5 and args.workload == "rep64k":
             # the S2 generator repeats itself exactly after 4 GiB (period i + 65536 equals period i): the tail of the
             # chunk is ONE match.  Time the part that carries the matcher's work on its own.

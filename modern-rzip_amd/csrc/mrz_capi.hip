@@ -42,6 +42,16 @@ static void mrz_make_hash_index(int64_t H[256]) {
 
 extern "C" int mrz_abi_version(void) { return MRZ_ABI_VERSION; }
 
+// Room for the emitted matches of a chunk of n bytes (24 B each).  Matches are >= 31 bytes and disjoint, so n / 31 + 2
+// always suffices -- 53 GB for a 64 GiB chunk, more than the chunk for a 256 GiB window.  Beyond MRZ_EVENT_CAP entries
+// (6.4 GB: one match per 256 bytes of a 64 GiB chunk; text emits one per ~400 bytes, the tar mix one per 500 KB) the
+// list is bounded instead; a chunk that would overflow it fails with MRZ_E_OVERFLOW (the sequencers stop at the cap).
+#define MRZ_EVENT_CAP (1ll << 28)
+static int64_t mrz_event_room(int64_t n) {
+    const int64_t worst = n / MRZ_MIN_MATCH + 2;
+    return worst < MRZ_EVENT_CAP ? worst : MRZ_EVENT_CAP;
+}
+
 extern "C" const char *mrz_strerror(int code) {
     switch (code) {
         case MRZ_OK: return "ok";
@@ -209,7 +219,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         if (const char *e = getenv("MRZ_DEEP_SCANNERS")) ctx->deep_scanners = atoi(e);
     }
     if (!rc && max_chunk > 0) {
-        rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, max_chunk / MRZ_MIN_MATCH + 2);
+        rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, mrz_event_room(max_chunk));
         if (!rc) rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(max_chunk));
         if (!rc) rc = mrz_fe_reserve(ctx, max_chunk / MRZ_TILE + 2, max_chunk);
     }
@@ -463,7 +473,7 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
     const uint8_t *d_buf = nullptr;
     int rc = mrz_stage_input(ctx, chunk, n, where, &d_buf);
     if (rc) return rc;
-    rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, n / MRZ_MIN_MATCH + 2);
+    rc = mrz_grow(ctx, &ctx->d_events, &ctx->event_cap, mrz_event_room(n));
     if (rc) return rc;
     rc = mrz_grow(ctx, &ctx->d_crc_parts, &ctx->crc_parts_cap, mrz_crc32_parts_needed(n));
     if (rc) return rc;
