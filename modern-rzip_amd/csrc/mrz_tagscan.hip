@@ -30,6 +30,8 @@
 #define MRZ_TS_THREADS 256
 #define MRZ_TS_PER_THREAD 16
 static_assert(MRZ_TS_THREADS * MRZ_TS_PER_THREAD == MRZ_TILE, "one workgroup per tile");
+#define MRZ_TS_TILES_PER_WG 8  // consecutive tiles a workgroup takes (hash_index is loaded into LDS once; 4096 positions
+                               // per workgroup made the launch, not the loads, the bound: 16.8 M workgroups per 64 GiB)
 
 // where a pass begins: behind the previous one, and not before the tile that holds the matcher's next position
 __device__ __forceinline__ int64_t mrz_fe_base(const mrz_seq_state *st) {
@@ -89,23 +91,23 @@ __global__ __launch_bounds__(MRZ_TS_THREADS) void mrz_fe_mark_kernel(const uint8
     int64_t want = (st->finished || st->error || end < base) ? 0 : ((end - base) >> MRZ_TILE_SHIFT) + 1;
     if (want > max_tiles) want = max_tiles;
     const int ntiles = (int)want;
-    const int tile = (int)blockIdx.x;
-    if (tile == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         hdr->base = base;
         hdr->mask = mask;
         hdr->p_done = p_done;
         hdr->ntiles = ntiles;
         hdr->T = 0;
     }
-    if (tile >= ntiles) return;
+    sH[tid] = hash_index[tid];
+    for (int tile = (int)blockIdx.x * MRZ_TS_TILES_PER_WG; tile < ((int)blockIdx.x + 1) * MRZ_TS_TILES_PER_WG && tile < ntiles; tile++) {
     const int64_t tile_pos = base + ((int64_t)tile << MRZ_TILE_SHIFT);
     // the sequencer never looks at positions <= its current p
     if (tile_pos + MRZ_TILE <= p_done + 1) {
         bitmap16[(int64_t)tile * MRZ_TS_THREADS + tid] = 0;
         if (tid == 0) tile_cnt[tile] = 0;
-        return;
+        continue;
     }
-    sH[tid] = hash_index[tid];
+    __syncthreads();  // (the previous tile's readers of sB / wsum are done)
     mrz_fe_stage(buf, n, tile_pos, sB, tid);
     __syncthreads();
 
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(MRZ_TS_THREADS) void mrz_fe_mark_kernel(const uint8
     if (tid == 0) {
         tile_cnt[tile] = total;
         if (total) atomicAdd(&grp_cnt[tile / MRZ_FE_GROUP], total);
+    }
     }
 }
 
@@ -202,18 +205,19 @@ __global__ __launch_bounds__(MRZ_TS_THREADS) void mrz_fe_emit_kernel(const uint8
     __shared__ __attribute__((aligned(16))) uint8_t sB[MRZ_TILE + 48];
     __shared__ int wsum[MRZ_TS_THREADS / 64];
     const int tid = threadIdx.x;
-    const int tile = (int)blockIdx.x;
-    if (tile >= hdr->T) return;
-    if (tile_cnt[tile] == 0) return;
+    const int T = hdr->T;
+    sH[tid] = hash_index[tid];
+    for (int tile = (int)blockIdx.x * MRZ_TS_TILES_PER_WG; tile < ((int)blockIdx.x + 1) * MRZ_TS_TILES_PER_WG && tile < T; tile++) {
+    if (tile_cnt[tile] == 0) continue;
     const int64_t tile_pos = hdr->base + ((int64_t)tile << MRZ_TILE_SHIFT);
     const uint32_t bits = bitmap16[(int64_t)tile * MRZ_TS_THREADS + tid];
-    sH[tid] = hash_index[tid];
+    __syncthreads();  // (the previous tile's readers of sB / wsum are done)
     mrz_fe_stage(buf, n, tile_pos, sB, tid);
     __syncthreads();
     int total;
     const int cnt = __popc(bits);
     const int incl = mrz_fe_block_incl(cnt, wsum, tid, &total);
-    if (!bits) return;
+    if (!bits) continue;
     const int64_t p0 = tile_pos + (int64_t)tid * MRZ_TS_PER_THREAD;
     const uint8_t *b = &sB[tid * MRZ_TS_PER_THREAD];
     int64_t t = 0;
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(MRZ_TS_THREADS) void mrz_fe_emit_kernel(const uint8
             dst[at++] = e;
         }
     }
+    }
 }
 
 // launcher (host): one pass over at most max_tiles tiles from where the device state says the last one ended
@@ -241,11 +246,12 @@ extern "C" hipError_t mrz_launch_frontend(hipStream_t stream, const uint8_t *buf
     const int ngroups = (max_tiles + MRZ_FE_GROUP - 1) / MRZ_FE_GROUP;
     hipError_t e = hipMemsetAsync(grp_cnt, 0, (size_t)ngroups * sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mrz_fe_mark_kernel, dim3((unsigned)max_tiles), dim3(MRZ_TS_THREADS), 0, stream, buf, n, hash_index, st,
+    const unsigned wgs = (unsigned)((max_tiles + MRZ_TS_TILES_PER_WG - 1) / MRZ_TS_TILES_PER_WG);
+    hipLaunchKernelGGL(mrz_fe_mark_kernel, dim3(wgs), dim3(MRZ_TS_THREADS), 0, stream, buf, n, hash_index, st,
                        max_tiles, hdr, bitmap16, tile_cnt, grp_cnt);
     hipLaunchKernelGGL(mrz_fe_scan_kernel, dim3((unsigned)ngroups), dim3(MRZ_FE_GROUP), 0, stream, st, hdr, n, cap, tile_cnt,
                        grp_cnt, tile_off);
-    hipLaunchKernelGGL(mrz_fe_emit_kernel, dim3((unsigned)max_tiles), dim3(MRZ_TS_THREADS), 0, stream, buf, n, hash_index, hdr,
+    hipLaunchKernelGGL(mrz_fe_emit_kernel, dim3(wgs), dim3(MRZ_TS_THREADS), 0, stream, buf, n, hash_index, hdr,
                        bitmap16, tile_cnt, tile_off, cand);
     return hipGetLastError();
 }
