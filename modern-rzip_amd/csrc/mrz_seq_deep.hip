@@ -45,9 +45,6 @@
 #define MRZ_SEQ_WAVES MRZ_DEEP_WAVES
 #include "mrz_seq_common.h"
 #include <cstddef>
-#ifdef MRZ_DEEP_TRACE
-#include <stdio.h>
-#endif
 
 #ifndef MRZ_DEEP_LANES
 #define MRZ_DEEP_LANES 256  // lanes of a batch
@@ -991,10 +988,6 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 // been scanned again (the round may end in the cooperative path, and the next one only knows ITS lanes' plans)
                 if (mine && i >= e2 && cmin < e2) S->R.flags[i] = (unsigned char)(f | MRZ_DF_STALE);
                 // R6: lanes [next, e2) commit as scanned (insert_hash + clean_one_from_hash, src/rzip.c:256-328,579-584)
-#ifdef MRZ_DEEP_TRACE
-                if (mine && i < e2 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
-                    printf("bulk q=%lld ins=%d kind=%d w=%d w2=%d cslot=%d nsame=%d lane=%d next=%d e2=%d\n", (long long)q, (int)a_ins, kind, w, w2, cslot, (int)S->R.nsame[i], i, next, e2);
-#endif
                 if (mine && i < e2) {
                     if (a_ins) {
                         int ws = w;
@@ -1136,10 +1129,6 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         const bool okc = rec ? mrz_deep_candidate_rec(C, L, S, cl, &nx_rec, lane, stat)
                                              : mrz_deep_coop(C, L, &S->coop, t, lane, stat);
                         ST_ADD(MRZ_ST_D_COOP, 1);
-#ifdef MRZ_DEEP_TRACE
-                        if (lane == 0 && q >= MRZ_DEEP_TRACE && q < MRZ_DEEP_TRACE + MRZ_DEEP_TRACE_LEN)
-                            printf("coop q=%lld -> p=%lld ev=%lld cur_len=%lld nw=%d lane=%d\n", (long long)q, (long long)L.p, (long long)L.n_events, (long long)L.cur_len, S->coop.n_written, cl);
-#endif
                         const bool same_masks = L.min_mask == mm0 && L.tag_mask == tm0;
                         const int nwr = rec ? 0 : mrz_uni(S->coop.n_written);
                         const int64_t cs = rec ? -1 : mrz_uni64(S->coop.cull_slot);

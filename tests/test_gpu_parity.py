@@ -447,6 +447,23 @@ def test_both_engines_pinned(gpu_lib, oracle, engine, monkeypatch):
     _parity.check_chunk(gpu_lib, oracle, _util.zipf_text(3 << 20, seed=8), level=9, table=True)
 
 
+@pytest.mark.parametrize("scanners", ["0", "3"])
+def test_deep_engine_scan_helper_counts(gpu_lib, oracle, scanners, monkeypatch):
+    """The deep engine without scan helpers and with three (default: up to 15): the lanes of a batch are dealt to however
+    many helpers have checked in; the result does not depend on it.  512 MiB of noise reaches a 7-bit mask (wide engine
+    first, which ends its launch where the mask reaches six bits); the tar mix adds real matches inside deep segments."""
+    monkeypatch.setenv("MRZ_DEEP_SCANNERS", scanners)
+    monkeypatch.setenv("MRZ_DEEP_MIN_BITS", "4")
+    data = w.noise(192 << 20, seed=21) + w.tar_like_fast(64 << 20, seed=22, pool_bytes=8 << 20)
+    want = oracle.rzip_chunk(data)
+    with m.RzipContext(lib=gpu_lib, max_chunk=len(data)) as ctx:
+        res, s0, s1 = ctx.rzip_chunk(data)
+        assert (s0, s1) == (want["s0"], want["s1"]) and res.stats.as_dict() == want["stats"] and res.crc32 == want["crc"]
+        assert res.min_mask == want["min_mask"] and res.hash_count == want["hash_count"]
+        t = ctx.timings()
+        assert 1 <= t.n_deep < t.n_segments
+
+
 def test_engines_alternate_within_one_chunk(gpu_lib, oracle):
     """Text, then a long stretch of one match after another, then noise: the per-segment choice changes engine in the
     middle of the chunk, the two kernels continue each other through the matcher state."""
