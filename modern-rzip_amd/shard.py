@@ -135,6 +135,44 @@ def rzip_file_chunk_chain_speculative(data, max_chunk, rank, world, rzip_chunk, 
     return [merged[k] for k in range(len(chunks))], total
 
 
+def rzip_file_chunks_on_ctxs(data, max_chunk, ctxs, predict=None):
+    """The chunks of ONE file through several ctxs of ONE process at the same time (one host thread and one XCD per ctx:
+    mrz_set_xcd), speculating on victim_round like rzip_file_chunk_chain_speculative: phase 1 runs every chunk with a
+    predicted value, `len(ctxs)` at a time; phase 2 walks the chunks in order with the true value and runs a chunk again
+    only where the prediction was wrong (the integer only moves on chain-limit evictions, src/rzip.c:284-289).
+    Returns ([(chunk_size, s0, s1), ...] in chunk order, number of re-runs): what the stream sink frames into the archive,
+    bit-identical to the one-ctx run."""
+    import threading
+    chunks = split_chunks(len(data), max_chunk)
+    predict = predict or (lambda k: 0)
+    spec = [None] * len(chunks)
+
+    def worker(j):
+        for k in range(j, len(chunks), len(ctxs)):
+            off, size = chunks[k]
+            c = ctxs[j]
+            c.victim_round = predict(k)
+            res, s0, s1 = c.rzip_chunk(data[off:off + size])
+            spec[k] = (predict(k), size, s0, s1, c.victim_round)
+    threads = [threading.Thread(target=worker, args=(j,)) for j in range(len(ctxs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    out, reruns, vr = [], 0, 0
+    for k, (off, size) in enumerate(chunks):
+        vin, size, s0, s1, vout = spec[k]
+        if vin != vr:  # mispredicted: once more with the true value
+            c = ctxs[0]
+            c.victim_round = vr
+            res, s0, s1 = c.rzip_chunk(data[off:off + size])
+            vout = c.victim_round
+            reruns += 1
+        out.append((size, s0, s1))
+        vr = vout
+    return out, reruns
+
+
 # ---- range-sharded front-end of ONE chunk (SURVEY.md 8e, second row) ------------------------
 # What shards inside a single window is everything except the sequencer: tag scan, CRC and literal gather work
 # on contiguous byte ranges (31-byte halo for the tags).  The pieces below are the host-side glue that is

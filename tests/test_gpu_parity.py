@@ -512,6 +512,12 @@ def test_eight_matchers_on_eight_xcds(gpu_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = json.loads(r.stdout.strip().splitlines()[-1])
     assert last == {"oracle_equal": True, "all_identical": True}, r.stdout[-2000:]
+    # ... and the chunks of ONE file through eight ctxs (victim_round chained speculatively): the oracle's archive
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_multictx.py"), "chunks", "16", "8", "8"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert last["archive_equals_oracle"] and last["reruns"] == 0, r.stdout[-2000:]
 
 
 def test_c_caller_program(gpu_lib, tmp_path):

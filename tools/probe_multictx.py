@@ -89,5 +89,42 @@ def main(argv):
     return lines
 
 
+def chunks_of_one_file(mib_per_chunk=32, n_chunks=8, n_ctxs=8):
+    """One file of n_chunks chunks (noise: victim_round never moves, every prediction holds) through n_ctxs ctxs on n_ctxs
+    XCDs of one process: the archive equals the oracle's; returns the JSON line."""
+    import hashlib as hl
+    import torch  # noqa: F401
+    import modern_rzip_amd as m
+    from modern_rzip_amd import shard, workloads as w
+    from tests import _util
+    lib = m.load_library()
+    o = _util.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+    max_chunk = mib_per_chunk << 20
+    data = w.noise(n_chunks * max_chunk - 12345, seed=77)
+    ramsize = max_chunk // 2 * 3
+    out = {}
+    for nc in (1, n_ctxs):
+        ctxs = [m.RzipContext(level=7, max_chunk=max_chunk, lib=lib) for _ in range(nc)]
+        for i, c in enumerate(ctxs):
+            c.set_xcd(i % 8)
+            c.set_farm_helpers(max(224 // nc - 8, 8))
+        t0 = time.perf_counter()
+        parts, reruns = shard.rzip_file_chunks_on_ctxs(data, max_chunk, ctxs)
+        dt = time.perf_counter() - t0
+        for c in ctxs:
+            c.close()
+        arch = o.frame(len(data), parts, hl.md5(data).digest(), ramsize=ramsize)
+        out[nc] = (dt, hl.sha256(arch).hexdigest(), reruns)
+    want, _, _ = o.compress(data, ramsize=ramsize)
+    line = {"file_mib": len(data) >> 20, "chunks": n_chunks, "ctxs": n_ctxs, "wall_s_1ctx": round(out[1][0], 3),
+            "wall_s": round(out[n_ctxs][0], 3), "speedup": round(out[1][0] / out[n_ctxs][0], 2), "reruns": out[n_ctxs][2],
+            "archive_equals_oracle": out[n_ctxs][1] == hl.sha256(want).hexdigest() == out[1][1]}
+    print(json.dumps(line), flush=True)
+    return line
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if sys.argv[1] == "chunks":
+        chunks_of_one_file(*[int(x) for x in sys.argv[2:]])
+    else:
+        main(sys.argv[1:])
