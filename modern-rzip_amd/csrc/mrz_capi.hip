@@ -215,7 +215,7 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         ctx->seq_wgs = 3;
         if (const char *e = getenv("MRZ_SEQ_WGS")) ctx->seq_wgs = atoi(e);
         if (hipMalloc(&ctx->d_deep_shared, mrz_seq_deep_shared_size()) != hipSuccess) rc = MRZ_E_NOMEM;
-        ctx->deep_scanners = 15;
+        ctx->deep_scanners = 63;
         if (const char *e = getenv("MRZ_DEEP_SCANNERS")) ctx->deep_scanners = atoi(e);
     }
     if (!rc && max_chunk > 0) {

@@ -390,15 +390,20 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
 // ---- scan helpers: more CUs for the SCAN phase ------------------------------------------------------------------------
 // The scan of a batch is read-only and most of what the engine costs at long runs (62 % of the kernel on the 64 GiB tar,
 // at 26 GB/s of table bytes: one CU's worth of loads in flight).  Up to MRZ_DEEP_SCANNERS more workgroups of the grid --
-// blocks xcd + 8, xcd + 16, ...: the committer's XCD under round-robin placement, CHECKED at run time (HW_REG_XCC_ID),
-// because they read the table through that XCD's L2 -- take a share of every batch's lanes: the committer posts the batch
+// ANY blocks but the committer's, on all eight XCDs -- take a share of every batch's lanes: the committer posts the batch
 // (positions, tags, masks) in device memory, every helper scans the lanes dealt to it into its own LDS and copies the
 // records out; the committer scans its own share meanwhile, waits for the helpers' lanes and copies their records in.
+// The XCDs' L2s are not coherent with each other, so everything that crosses travels release -> flag -> acquire at
+// agent scope: the committer's table stores of the commits before (every wave's vmcnt(0), a barrier, ONE release fence =
+// the write-back of its XCD's L2) before the batch's sequence number is stored; a helper's acquire fence (its L1 and its
+// XCD's L2 give up what they held) after it has seen the number and before it reads the job or the table; the same the
+// other way round for the records.  What a helper reads of the table is then the state at the post -- the state the
+// committer's own scan sees --, and the table is not written again before the batch's lanes are all back.
 // Rescans, conflicts and the commit stay the committer's.  A helper that is not there (not resident, another XCD, a
 // launch without spare blocks) is simply not dealt any lanes: helpers check in with a ticket and the committer counts
 // who has.  All spins are bounded or end with the launch (quit).
 #ifndef MRZ_DEEP_SCANNERS
-#define MRZ_DEEP_SCANNERS 15
+#define MRZ_DEEP_SCANNERS 63
 #endif
 #ifndef MRZ_DEEP_HELP_MIN
 #define MRZ_DEEP_HELP_MIN 48  // lanes a batch must have before it is dealt out
@@ -468,7 +473,7 @@ __device__ static void mrz_deep_scan_helper(const mrz_cfg &C, mrz_deep_lds *S, m
                !__hip_atomic_load(&G->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && spins++ < (1ll << 24))
             __builtin_amdgcn_s_sleep(8);
         int ticket = -1;
-        if (x != 0 && (int)x - 1 == (int)MRZ_DEEP_XCC_ID())
+        if (x != 0)
             ticket = (int)__hip_atomic_fetch_add(&G->n_ok, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         S->ctl[0] = ticket;
     }
@@ -632,8 +637,8 @@ __device__ __forceinline__ int mrz_deep_first(bool flag, int *wm, int lane, int 
 __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_args a, mrz_deep_shared *G, int scanners) {
 #ifdef MRZ_EMU_LDS_PER_BLOCK
     // (the CPU emulator of the test suite keeps `__shared__` in one static copy: one per workgroup that has a role here)
-    static mrz_deep_lds deep_all[1 + MRZ_DEEP_SCANNERS];
-    mrz_deep_lds *S = &deep_all[(blockIdx.x / 8) % (1 + MRZ_DEEP_SCANNERS)];
+    static mrz_deep_lds deep_all[1 + 15];
+    mrz_deep_lds *S = &deep_all[(blockIdx.x / 8) % (1 + 15)];
 #else
     __shared__ mrz_deep_lds deep;
     mrz_deep_lds *S = &deep;
@@ -646,7 +651,13 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
     const int xcd = a.xcd & 7;
     const int bx = (int)blockIdx.x;
     const bool is_seq = bx == xcd;
+#ifdef MRZ_EMU_LDS_PER_BLOCK
     const bool is_scanner = G != nullptr && !is_seq && bx % 8 == xcd && bx / 8 >= 1 && bx / 8 <= scanners && bx / 8 <= MRZ_DEEP_SCANNERS;
+#else
+    // (any block but the committer's: the table, the job and the records travel through release / acquire at agent scope,
+    // which holds across XCDs)
+    const bool is_scanner = G != nullptr && !is_seq && (bx < xcd ? bx : bx - 1) < scanners && scanners <= MRZ_DEEP_SCANNERS;
+#endif
 #if MRZ_HELPER_WGS > 0
     if (!is_seq && !is_scanner) {
         if (a.gmailbox) mrz_helper_wg(a.buf, (mrz_gmailbox *)a.gmailbox);
@@ -1257,7 +1268,7 @@ extern "C" hipError_t mrz_launch_sequencer_deep(hipStream_t stream, const uint8_
         emu::request_coresident();
     }
 #else
-    while (scanners > 0 && grid < (unsigned)(8 * scanners + a.xcd + 1)) scanners--;  // (blocks there are)
+    while (scanners > 0 && grid < (unsigned)(scanners + 2)) scanners--;  // (blocks there are)
 #endif
     if (deep_shared) {
         hipError_t e = hipMemsetAsync(deep_shared, 0, offsetof(mrz_deep_shared, R), stream);
