@@ -95,6 +95,7 @@ struct mrz_deep_lds {
     mrz_deep_recs R;
     int idx[MRZ_DEEP_LANES];                                  // the lane's entry of the candidate list
     int cmin[MRZ_DEEP_LANES];                                 // first lane of the round that touches what this one depends on
+    int cpos[MRZ_DEEP_LANES];                                 // where along its walk a stale lane's scan has to be taken up again
     int xw_n;                                                 // slots the cooperative path has written in this batch
     int xw_slot[MRZ_DEEP_XW];
     unsigned short rescan_list[MRZ_DEEP_LANES];
@@ -242,8 +243,13 @@ __device__ __forceinline__ int mrz_deep_cw_slot(const mrz_deep_lds *S, int64_t c
 static_assert(MRZ_DEEP_CW_WORDS == 32, "mrz_deep_cw_slot searches 32 words in 5 steps");
 
 // ---- SCAN of one lane by one wave ---------------------------------------------------------------------------------
+// `from` > 0: a CONTINUATION -- the lane has been scanned before and all that has changed since is a slot at walk
+// position `from` or behind (an earlier lane took the slot it wanted to write, or filled its first empty slot): what the
+// walk found before that position stands (the precise dependency rule: no other write there matters), so the run is
+// taken up again AT that slot instead of being read from its start -- one or two loads instead of 20-170 at masks of 11+
+// bits, where most conflicts are several inserters of one run wanting the same slot.
 __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, int64_t better, int64_t tag_mask,
-                                     int64_t clean_ptr, int xw_n, int lane) {
+                                     int64_t clean_ptr, int xw_n, int lane, int from = 0) {
     const mrz_slot *tab = C.tab;
     const uint8_t *__restrict__ buf = C.buf;
     const int smask = (int)C.slot_mask;
@@ -256,6 +262,27 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
     int nsame = 0, round = 0;
     bool cplx = false;
     int64_t occ_t = 0, occ_off = 0, old_t = 0;
+    bool cont = false, insert_kept = false;
+    int nsame0 = 0;
+    if (from > 0) {
+        const int f0 = mrz_uni((int)S->R.flags[i]), k0 = mrz_uni((int)S->R.kind[i]);
+        const int ns0 = mrz_uni((int)S->R.nsame[i]);
+        // (evictions and displacements carry state that is not kept per position: those lanes are read from the start)
+        if (!(f0 & MRZ_DF_CPLX) && k0 != MRZ_DK_EVICT && k0 != MRZ_DK_DISPLACE && from <= ((mrz_uni(S->R.fe[i]) - h) & smask)) {
+            cont = true;
+            // the tag-equal entries before `from` stay (they are in probe order)
+            const bool before = lane < ns0 && ((S->R.same_slot[i][lane < MRZ_SMAX ? lane : 0] - h) & smask) < from;
+            nsame0 = nsame = __popcll(__ballot(before));
+            if (ins && (k0 == MRZ_DK_EMPTY || k0 == MRZ_DK_OVER) && ((mrz_uni(S->R.w[i]) - h) & smask) < from) {
+                insert_kept = true;  // the insert's place lies before the change: it stands
+                kind = k0;
+                w = mrz_uni(S->R.w[i]);
+                old_t = mrz_uni64(S->R.old_t[i]);
+            } else
+                round = nsame;  // tag-equal entries the walk has passed so far
+        }
+    }
+    const int start = cont ? from : 0;
     const int max_groups = (int)((C.nslots + 64 * MRZ_DEEP_GROUP - 1) / (64 * MRZ_DEEP_GROUP)) + 1;
     for (int grp = 0; fe < 0; grp++) {
         if (grp >= max_groups) {  // cannot happen: the table is at most 2/3 full
@@ -264,7 +291,7 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
             break;
         }
         mrz_slot e[MRZ_DEEP_GROUP];
-        const int s0 = h + grp * (64 * MRZ_DEEP_GROUP) + lane;
+        const int s0 = h + start + grp * (64 * MRZ_DEEP_GROUP) + lane;
 #pragma unroll
         for (int g = 0; g < MRZ_DEEP_GROUP; g++) e[g] = tab[(s0 + g * 64) & smask];
 #pragma unroll
@@ -364,9 +391,9 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
     }
     // 64-byte probes of the tag-equal entries, one per lane
     const int ns = nsame < MRZ_SMAX ? nsame : MRZ_SMAX;
-    if (ns) {
+    if (ns > nsame0) {
         MRZ_WAVE_SYNC();
-        if (lane < ns) S->R.raw[i][lane] = (unsigned short)mrz_deep_probe_raw(buf, q, S->R.same_off[i][lane], C.end);
+        if (lane >= nsame0 && lane < ns) S->R.raw[i][lane] = (unsigned short)mrz_deep_probe_raw(buf, q, S->R.same_off[i][lane], C.end);
     }
     if (lane == 0) {
         S->R.h[i] = h;
@@ -382,8 +409,10 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
         S->R.old_t2[i] = old_t2;
         S->R.nsame[i] = (unsigned char)ns;
         S->R.flags[i] = (unsigned char)((ins ? MRZ_DF_INS : 0) | (cplx ? MRZ_DF_CPLX : 0));
-        S->R.cp_scan[i] = clean_ptr;
-        S->R.xw_seen[i] = (unsigned short)xw_n;
+        if (!cont) {  // (a continuation keeps the older of the two states for what it did not read again)
+            S->R.cp_scan[i] = clean_ptr;
+            S->R.xw_seen[i] = (unsigned short)xw_n;
+        }
     }
 }
 
@@ -460,8 +489,6 @@ __device__ __forceinline__ void mrz_deep_rec_copy(mrz_deep_recs *dst, const mrz_
     }
 }
 
-__device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, int64_t better, int64_t tag_mask,
-                                     int64_t clean_ptr, int xw_n, int lane);
 
 // a scan helper workgroup: see above
 __device__ static void mrz_deep_scan_helper(const mrz_cfg &C, mrz_deep_lds *S, mrz_deep_shared *G, int tid, int lane, int wave) {
@@ -890,6 +917,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 __syncthreads();
                 // R3: who depends on an earlier lane's writes; who needs the cooperative path
                 int cmin = 0x7fffffff;
+                int cfrom = 0x7fffffff;  // walk position from which a conflicting lane's scan has to be redone (0: all of it)
                 int stop = 0;
                 const int64_t cw_base = L.clean_ptr;
                 const int cw_len = MRZ_DEEP_CW_WORDS * 64;
@@ -900,17 +928,25 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         int m;
                         m = mrz_deep_smap_get(S, fe);
                         cmin = m < cmin ? m : cmin;
+                        if (m < i) cfrom = (fe - h) & smask;  // its first empty slot gets filled: the walk goes on from there
                         m = mrz_deep_tmap_get(S, t);
                         if (m != i) cmin = m < cmin ? m : cmin;
+                        if (m < i) cfrom = 0;  // an entry of its tag somewhere in the run: all of it
                         if (wr_w) {
                             m = mrz_deep_smap_get(S, w);
                             if (m != i) cmin = m < cmin ? m : cmin;
+                            if (m < i) {  // the slot it wanted is taken: the walk goes on from there
+                                const int pw_ = (w - h) & smask;
+                                cfrom = pw_ < cfrom ? pw_ : cfrom;
+                            }
                         }
                         if (wr_w2) {
                             m = mrz_deep_smap_get(S, w2);
                             if (m != i) cmin = m < cmin ? m : cmin;
+                            if (m < i) cfrom = 0;
                             m = mrz_deep_tmap_get(S, occ_t);
                             if (m != i) cmin = m < cmin ? m : cmin;
+                            if (m < i) cfrom = 0;
                         }
                         if (cmin < i || (f & MRZ_DF_STALE)) stop |= MRZ_DS_CONFLICT;
                         // a real match (or a compare beyond the 64-byte reach) among the tag-equal entries
@@ -997,7 +1033,11 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 if (mine && i == e2) S->ctl[4] = stop;
                 // a lane behind the committed ones that depends on what one of them has written stays marked until it has
                 // been scanned again (the round may end in the cooperative path, and the next one only knows ITS lanes' plans)
-                if (mine && i >= e2 && cmin < e2) S->R.flags[i] = (unsigned char)(f | MRZ_DF_STALE);
+                if (mine && i >= e2 && cmin < e2) {
+                    const int old = (f & MRZ_DF_STALE) ? S->cpos[i] : 0x7fffffff;
+                    S->cpos[i] = cfrom < old ? cfrom : old;
+                    S->R.flags[i] = (unsigned char)(f | MRZ_DF_STALE);
+                }
                 // R6: lanes [next, e2) commit as scanned (insert_hash + clean_one_from_hash, src/rzip.c:256-328,579-584)
                 if (mine && i < e2) {
                     if (a_ins) {
@@ -1084,9 +1124,10 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         // lanes at or behind `next` whose scan no longer holds -- an earlier lane that HAS committed touched
                         // what they depend on, or the sweep has reached into what they read -- are scanned again, all at
                         // once, against the table as it is now
-                        bool again = false;
+                        bool again = false, by_flag = false;
                         if (i >= next && i < nb && !(S->R.flags[i] & MRZ_DF_CPLX)) {
                             again = (S->R.flags[i] & MRZ_DF_STALE) != 0;
+                            by_flag = again;
                             {
                                 const int hh = S->R.h[i], ff = S->R.fe[i], hh2 = S->R.h2[i], ww2 = S->R.w2[i];
                                 const bool dsp = (S->R.flags[i] & MRZ_DF_INS) && S->R.kind[i] == MRZ_DK_DISPLACE;
@@ -1108,6 +1149,25 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                                 }
                             }
                         }
+                        // (a slot the cooperative path has written, or a cull, inside what the lane read: all of it again)
+                        if (again && i >= next && i < nb) {
+                            bool other = false;
+                            {
+                                const int hh = S->R.h[i], ff = S->R.fe[i], hh2 = S->R.h2[i], ww2 = S->R.w2[i];
+                                const bool dsp = (S->R.flags[i] & MRZ_DF_INS) && S->R.kind[i] == MRZ_DK_DISPLACE;
+                                for (int k = S->R.xw_seen[i]; k < xw_n && !other; k++) {
+                                    const int xs = S->xw_slot[k];
+                                    other = (((xs - hh) & smask) <= ((ff - hh) & smask)) || (dsp && (((xs - hh2) & smask) <= ((ww2 - hh2) & smask)));
+                                }
+                                const int64_t cp0 = S->R.cp_scan[i];
+                                if (!other && L.clean_ptr != cp0) {
+                                    const int lc = (int)(L.clean_ptr - cp0) + 1;
+                                    other = mrz_deep_ranges_meet(hh, ((ff - hh) & smask) + 1, (int)cp0, lc, smask) ||
+                                            (dsp && mrz_deep_ranges_meet(hh2, ((ww2 - hh2) & smask) + 1, (int)cp0, lc, smask));
+                                }
+                            }
+                            if (!by_flag || other) S->cpos[i] = 0;
+                        }
                         if (tid == 0) S->n_rescan = 0;
                         __syncthreads();
                         if (again) S->rescan_list[atomicAdd(&S->n_rescan, 1)] = (unsigned short)i;
@@ -1115,8 +1175,11 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         const int nr = S->n_rescan;
                         ST_ADD(MRZ_ST_D_ROUNDS, 1);
                         ST_ADD(MRZ_ST_D_RESCANNED, nr);
-                        for (int k = wave; k < nr; k += MRZ_DEEP_WAVES)
-                            mrz_deep_scan(C, S, (int)S->rescan_list[k], better, L.tag_mask, L.clean_ptr, xw_n, lane);
+                        for (int k = wave; k < nr; k += MRZ_DEEP_WAVES) {
+                            const int li = (int)S->rescan_list[k];
+                            const int cf = mrz_uni(S->cpos[li]);
+                            mrz_deep_scan(C, S, li, better, L.tag_mask, L.clean_ptr, xw_n, lane, cf == 0x7fffffff ? 0 : cf);
+                        }
                         __syncthreads();
                         PROF_ADD(MRZ_ST_D_T_RESCAN);
                     }
