@@ -1331,6 +1331,7 @@ extern "C" hipError_t mrz_launch_sequencer_deep(hipStream_t stream, const uint8_
         emu::request_coresident();
     }
 #else
+    if (scanners > a.n_helpers / 2) scanners = a.n_helpers / 2;  // (the other half stays with the compare farm)
     while (scanners > 0 && grid < (unsigned)(scanners + 2)) scanners--;  // (blocks there are)
 #endif
     if (deep_shared) {
