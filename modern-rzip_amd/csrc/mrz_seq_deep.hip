@@ -873,6 +873,13 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
         __syncthreads();
         PROF_ADD(MRZ_ST_D_T_SCAN);
         // ---- COMMIT: rounds ------------------------------------------------------------------------------------------
+        for (int k = tid; k < MRZ_DEEP_MAP; k += MRZ_DEEP_THREADS) {  // (every round clears the maps behind itself)
+            S->smap_key[k] = 0u;
+            S->smap_lane[k] = 0x7fffffff;
+            S->tmap_key[k] = 0ull;
+            S->tmap_lane[k] = 0x7fffffff;
+        }
+        __syncthreads();
         int next = 0;       // first lane not dealt with
         bool cut = false;   // the rest of the batch is void (the masks have moved): form again
         int xw_n = 0;       // slots the cooperative path has written since the batch was scanned (S->xw_slot)
@@ -887,14 +894,22 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 // the next candidate: the cooperative path takes it
                 coop_lane = next;
             } else {
-                // R1/R2: the maps of what the lanes [next, nb) plan to write
-                for (int k = tid; k < MRZ_DEEP_MAP; k += MRZ_DEEP_THREADS) {
-                    S->smap_key[k] = 0u;
-                    S->smap_lane[k] = 0x7fffffff;
-                    S->tmap_key[k] = 0ull;
-                    S->tmap_lane[k] = 0x7fffffff;
+                // the cull window's slots are asked for now (clean_one_from_hash's sweep, src/rzip.c:313-321: 32 x 64 slots
+                // ahead of tag_clean_ptr) and looked at after the conflicts have been found: one trip to memory behind the
+                // LDS work of R2 / R3
+                const int64_t cw_base = L.clean_ptr;
+                const bool load_cw = L.count + (nb - next) > C.limit;
+                constexpr int CW_PER_WAVE = (MRZ_DEEP_CW_WORDS + MRZ_DEEP_WAVES - 1) / MRZ_DEEP_WAVES;
+                mrz_slot cwe[CW_PER_WAVE];
+#pragma unroll
+                for (int b = 0; b < CW_PER_WAVE; b++) {
+                    cwe[b].off = 0;
+                    cwe[b].t = 0;
+                    const int wi = b * MRZ_DEEP_WAVES + wave;
+                    const int64_t slot = cw_base + (int64_t)wi * 64 + lane;
+                    if (load_cw && wi < MRZ_DEEP_CW_WORDS && slot < C.nslots) cwe[b] = C.tab[slot];
                 }
-                __syncthreads();
+                // R2: the maps of what the lanes [next, nb) plan to write (cleared at the end of the round before)
                 const int f = mine ? S->R.flags[i] : 0;
                 const bool ins = mine && (f & MRZ_DF_INS), cplx = mine && (f & MRZ_DF_CPLX);
                 const int kind = mine ? S->R.kind[i] : MRZ_DK_NONE, kind2 = mine ? S->R.kind2[i] : MRZ_DK_NONE;
@@ -919,7 +934,6 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 int cmin = 0x7fffffff;
                 int cfrom = 0x7fffffff;  // walk position from which a conflicting lane's scan has to be redone (0: all of it)
                 int stop = 0;
-                const int64_t cw_base = L.clean_ptr;
                 const int cw_len = MRZ_DEEP_CW_WORDS * 64;
                 if (mine) {
                     if (cplx)
@@ -974,22 +988,20 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     S->cmin[i] = cmin;
                 }
                 int e1 = mrz_deep_first(mine && stop != 0, S->wmin, lane, wave, tid, nb);
-                // R4: the cull window (only when this round can reach the limit)
-                const bool want_cw = L.count + (e1 - next) > C.limit;
-                if (want_cw) {
-                    for (int b = 0; b < MRZ_DEEP_CW_WORDS / MRZ_DEEP_WAVES + (MRZ_DEEP_CW_WORDS % MRZ_DEEP_WAVES ? 1 : 0); b++) {
-                        const int wi = b * MRZ_DEEP_WAVES + wave;
-                        if (wi >= MRZ_DEEP_CW_WORDS) break;
-                        const int64_t slot = cw_base + (int64_t)wi * 64 + lane;
-                        mrz_slot e;
-                        e.off = 0;
-                        e.t = 0;
-                        if (slot < C.nslots) e = C.tab[slot];
-                        const mrz_u64 m = __ballot(((e.off | e.t) != 0) && ((e.t & better) != better));
-                        if (lane == 0) S->cw[wi] = m;
-                    }
-                } else if (tid < MRZ_DEEP_CW_WORDS)
-                    S->cw[tid] = 0ull;
+                // (every thread has read the maps: they are cleared for the next round now)
+                for (int k = tid; k < MRZ_DEEP_MAP; k += MRZ_DEEP_THREADS) {
+                    S->smap_key[k] = 0u;
+                    S->smap_lane[k] = 0x7fffffff;
+                    S->tmap_key[k] = 0ull;
+                    S->tmap_lane[k] = 0x7fffffff;
+                }
+                // R4: the cull window's failing entries (all-zero words when this round cannot reach the limit)
+#pragma unroll
+                for (int b = 0; b < CW_PER_WAVE; b++) {
+                    const int wi = b * MRZ_DEEP_WAVES + wave;
+                    const mrz_u64 m = __ballot(((cwe[b].off | cwe[b].t) != 0) && ((cwe[b].t & better) != better));
+                    if (lane == 0 && wi < MRZ_DEEP_CW_WORDS) S->cw[wi] = m;
+                }
                 __syncthreads();
                 if (wave == 0) {
                     const int c = lane < MRZ_DEEP_CW_WORDS ? __popcll(S->cw[lane]) : 0;
