@@ -67,6 +67,7 @@ enum { MRZ_DK_NONE = 255, MRZ_DK_EMPTY = 0, MRZ_DK_OVER = 1, MRZ_DK_DISPLACE = 2
 #define MRZ_DF_INS 1
 #define MRZ_DF_CPLX 2
 #define MRZ_DF_STALE 4   // an earlier lane that has committed since touched what the scan depends on: scan again
+#define MRZ_DF_FE2 8     // the slot behind the first empty one is empty too
 // why a lane stops a round
 #define MRZ_DS_COOP 1      // needs the cooperative path (a real match, a cascade, too many tag-equal entries, a write into the cull window)
 #define MRZ_DS_CONFLICT 2  // an earlier lane of the round touches what its scan depends on
@@ -79,9 +80,13 @@ struct mrz_deep_recs {
     int64_t occ_t[MRZ_DEEP_LANES], occ_off[MRZ_DEEP_LANES];  // the occupant a displacing lane moves
     int64_t old_t[MRZ_DEEP_LANES], old_t2[MRZ_DEEP_LANES];   // tags the lane's stores overwrite (0: none)
     int64_t cp_scan[MRZ_DEEP_LANES];                         // tag_clean_ptr when the lane was scanned
+    int64_t alt_old_t[MRZ_DEEP_LANES];                       // ... and the tag a store to alt_w overwrites
+    int alt_w[MRZ_DEEP_LANES];                                // where the insert's walk stops NEXT if the slot it wanted holds a
+                                                              // higher-ranked tag by then (-1: unknown / something else happens)
     int h[MRZ_DEEP_LANES], fe[MRZ_DEEP_LANES], w[MRZ_DEEP_LANES], h2[MRZ_DEEP_LANES], w2[MRZ_DEEP_LANES];
     unsigned short xw_seen[MRZ_DEEP_LANES];                   // cooperative-path writes of this batch the lane's scan has seen
     unsigned char kind[MRZ_DEEP_LANES], kind2[MRZ_DEEP_LANES], nsame[MRZ_DEEP_LANES], flags[MRZ_DEEP_LANES];
+    unsigned char alt_kind[MRZ_DEEP_LANES];
     int same_slot[MRZ_DEEP_LANES][MRZ_SMAX];
     int64_t same_off[MRZ_DEEP_LANES][MRZ_SMAX];
     unsigned short raw[MRZ_DEEP_LANES][MRZ_SMAX];             // mrz_deep_probe_raw of every tag-equal entry
@@ -262,8 +267,12 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
     int nsame = 0, round = 0;
     bool cplx = false;
     int64_t occ_t = 0, occ_off = 0, old_t = 0;
-    bool cont = false, insert_kept = false;
+    bool cont = false, insert_kept = false, fe2 = false;
     int nsame0 = 0;
+    // the NEXT place the insert's walk would stop at, should the slot it wants be taken by a tag it passes (another inserter
+    // of the same run, earlier in the batch): the second inserter then needs no second look at the run
+    int alt_w = -1, alt_kind = MRZ_DK_NONE, alt_st = 0, alt_round = 0;  // alt_st: 0 not looking, 1 looking, 2 settled
+    int64_t alt_old_t = 0;
     if (from > 0) {
         const int f0 = mrz_uni((int)S->R.flags[i]), k0 = mrz_uni((int)S->R.kind[i]);
         const int ns0 = mrz_uni((int)S->R.nsame[i]);
@@ -303,9 +312,13 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
             const int fe_idx = m_empty ? __ffsll((long long)m_empty) - 1 : 64;
             const mrz_u64 valid = mrz_low_mask(fe_idx);
             const mrz_u64 m_same = __ballot(!empty && e[g].t == t) & valid;
+            mrz_u64 m_due = 0, m_low = 0;
+            if (kind == -1 || alt_st == 1) {
+                m_due = __ballot(!empty && (e[g].t & better) != better) & valid;
+                m_low = __ballot(!empty && mrz_ones_rank(e[g].t) < my_rank) & valid & ~m_due;
+            }
+            int alt_from = 0;  // first slot of this block the search for the next stop looks at
             if (kind == -1) {
-                const mrz_u64 m_due = __ballot(!empty && (e[g].t & better) != better) & valid;
-                const mrz_u64 m_low = __ballot(!empty && mrz_ones_rank(e[g].t) < my_rank) & valid & ~m_due;
                 const mrz_u64 m_stop = m_due | m_low;
                 const int ks = m_stop ? __ffsll((long long)m_stop) - 1 : 64;
                 const int nq = __popcll(m_same & mrz_low_mask(ks));
@@ -318,6 +331,9 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
                         if ((m_due >> ks) & 1) {
                             kind = MRZ_DK_OVER;
                             old_t = mrz_bcast64(e[g].t, ks);
+                            alt_st = 1;
+                            alt_from = ks + 1;
+                            alt_round = round;
                         } else {
                             kind = MRZ_DK_DISPLACE;
                             occ_t = mrz_bcast64(e[g].t, ks);
@@ -326,6 +342,35 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
                     } else if (fe_idx < 64) {
                         w = (sb + fe_idx) & smask;
                         kind = MRZ_DK_EMPTY;
+                        // (behind a first empty slot that somebody else fills: the slot after it, if that is empty too)
+                        if (fe_idx < 63 && ((m_empty >> (fe_idx + 1)) & 1)) {
+                            alt_w = (sb + fe_idx + 1) & smask;
+                            alt_kind = MRZ_DK_EMPTY;
+                        }
+                        alt_st = 2;
+                    }
+                }
+            }
+            if (alt_st == 1 && alt_from < 64) {
+                const mrz_u64 beyond = ~mrz_low_mask(alt_from);
+                const mrz_u64 m_stop2 = (m_due | m_low) & beyond;
+                const int ks2 = m_stop2 ? __ffsll((long long)m_stop2) - 1 : 64;
+                const int nq2 = __popcll(m_same & beyond & mrz_low_mask(ks2));
+                if (alt_round + nq2 >= max_chain)
+                    alt_st = 2;  // (the chain limit comes first: an eviction, not a plain stop)
+                else {
+                    alt_round += nq2;
+                    if (ks2 < 64) {
+                        if ((m_due >> ks2) & 1) {
+                            alt_w = (sb + ks2) & smask;
+                            alt_kind = MRZ_DK_OVER;
+                            alt_old_t = mrz_bcast64(e[g].t, ks2);
+                        }
+                        alt_st = 2;  // (a lower-ranked occupant: a displacement, not recorded)
+                    } else if (fe_idx < 64) {
+                        alt_w = (sb + fe_idx) & smask;
+                        alt_kind = MRZ_DK_EMPTY;
+                        alt_st = 2;
                     }
                 }
             }
@@ -339,7 +384,10 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
                 }
                 nsame += __popcll(m_same);
             }
-            if (fe_idx < 64) fe = (sb + fe_idx) & smask;
+            if (fe_idx < 64) {
+                fe = (sb + fe_idx) & smask;
+                fe2 = fe_idx < 63 && ((m_empty >> (fe_idx + 1)) & 1);
+            }
         }
     }
     if (nsame > MRZ_SMAX) cplx = true;
@@ -407,8 +455,11 @@ __device__ static void mrz_deep_scan(const mrz_cfg &C, mrz_deep_lds *S, int i, i
         S->R.occ_off[i] = occ_off;
         S->R.old_t[i] = old_t;
         S->R.old_t2[i] = old_t2;
+        S->R.alt_w[i] = (cplx || kind == MRZ_DK_DISPLACE || kind == MRZ_DK_EVICT || insert_kept) ? -1 : alt_w;
+        S->R.alt_kind[i] = (unsigned char)alt_kind;
+        S->R.alt_old_t[i] = alt_old_t;
         S->R.nsame[i] = (unsigned char)ns;
-        S->R.flags[i] = (unsigned char)((ins ? MRZ_DF_INS : 0) | (cplx ? MRZ_DF_CPLX : 0));
+        S->R.flags[i] = (unsigned char)((ins ? MRZ_DF_INS : 0) | (cplx ? MRZ_DF_CPLX : 0) | (fe2 ? MRZ_DF_FE2 : 0));
         if (!cont) {  // (a continuation keeps the older of the two states for what it did not read again)
             S->R.cp_scan[i] = clean_ptr;
             S->R.xw_seen[i] = (unsigned short)xw_n;
@@ -471,6 +522,9 @@ __device__ __forceinline__ void mrz_deep_rec_copy(mrz_deep_recs *dst, const mrz_
     dst->old_t[i] = src->old_t[i];
     dst->old_t2[i] = src->old_t2[i];
     dst->cp_scan[i] = src->cp_scan[i];
+    dst->alt_old_t[i] = src->alt_old_t[i];
+    dst->alt_w[i] = src->alt_w[i];
+    dst->alt_kind[i] = src->alt_kind[i];
     dst->h[i] = src->h[i];
     dst->fe[i] = src->fe[i];
     dst->w[i] = src->w[i];
@@ -930,7 +984,47 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     }
                 }
                 __syncthreads();
-                // R3: who depends on an earlier lane's writes; who needs the cooperative path
+                // R3a: a lane whose ONLY trouble is that an earlier lane takes the slot it wanted (the first due entry of the
+                // same run -- every inserter of a run stops there) or fills its first empty slot knows from its scan what it
+                // finds instead: the next stop of its walk (alt_w), one slot more for the look-up. It plans that now.
+                //   res & 1: the insert goes to alt_w;  res & 2: the look-up ends one slot later (fe + 1)
+                int res = 0, res_x = -1;
+                int w_e = w, kind_e = kind, fe_e = fe;
+                if (mine && !cplx && !(f & MRZ_DF_STALE) && kind != MRZ_DK_DISPLACE) {
+                    const int m_t = mrz_deep_tmap_get(S, t);
+                    const int m_fe = mrz_deep_smap_get(S, fe);
+                    const int m_w = wr_w ? mrz_deep_smap_get(S, w) : 0x7fffffff;
+                    const bool c_w = wr_w && m_w < i, c_fe = m_fe < i;
+                    if (m_t >= i && (c_w || c_fe)) {
+                        bool can = true;
+                        const int aw = S->R.alt_w[i], ak = S->R.alt_kind[i];
+                        if (c_w) {
+                            const int x = m_w;
+                            res_x = x;
+                            const int kx = S->R.kind[x];
+                            can = aw >= 0 && S->R.w[x] == w && (kx == MRZ_DK_EMPTY || kx == MRZ_DK_OVER) &&
+                                  mrz_ones_rank(S->R.t[x]) >= mrz_ones_rank(t);
+                            res |= 1;
+                            if (kind == MRZ_DK_EMPTY) res |= 2;  // (w == fe: aw == fe + 1, empty)
+                        }
+                        if (c_fe && !(res & 2)) {
+                            // somebody fills the first empty slot: the look-up passes that entry (another tag: the tag map
+                            // says so) and ends at the next slot, if that is empty; an insert that was to end there cannot
+                            can = can && (f & MRZ_DF_FE2) && !((res & 1) && ak == MRZ_DK_EMPTY);
+                            res |= 2;
+                        }
+                        if (!can) res = 0;
+                    }
+                    if (res & 1) {
+                        w_e = S->R.alt_w[i];
+                        kind_e = S->R.alt_kind[i];
+                        mrz_deep_smap_put(S, w_e, i);
+                        if (kind_e == MRZ_DK_OVER) mrz_deep_tmap_put(S, S->R.alt_old_t[i], i);
+                    }
+                    if (res & 2) fe_e = (fe + 1) & smask;
+                }
+                __syncthreads();
+                // R3b: who depends on an earlier lane's writes; who needs the cooperative path
                 int cmin = 0x7fffffff;
                 int cfrom = 0x7fffffff;  // walk position from which a conflicting lane's scan has to be redone (0: all of it)
                 int stop = 0;
@@ -940,48 +1034,65 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         stop |= MRZ_DS_COOP;
                     else {
                         int m;
+                        bool hard = false;  // a dependence the lane has no answer to
                         m = mrz_deep_smap_get(S, fe);
                         cmin = m < cmin ? m : cmin;
-                        if (m < i) cfrom = (fe - h) & smask;  // its first empty slot gets filled: the walk goes on from there
+                        if (m < i) {
+                            cfrom = (fe - h) & smask;  // its first empty slot gets filled: the walk goes on from there
+                            if (!(res & 2)) hard = true;
+                        }
                         m = mrz_deep_tmap_get(S, t);
                         if (m != i) cmin = m < cmin ? m : cmin;
-                        if (m < i) cfrom = 0;  // an entry of its tag somewhere in the run: all of it
+                        if (m < i) {
+                            cfrom = 0;  // an entry of its tag somewhere in the run: all of it
+                            hard = true;
+                        }
                         if (wr_w) {
                             m = mrz_deep_smap_get(S, w);
                             if (m != i) cmin = m < cmin ? m : cmin;
                             if (m < i) {  // the slot it wanted is taken: the walk goes on from there
                                 const int pw_ = (w - h) & smask;
                                 cfrom = pw_ < cfrom ? pw_ : cfrom;
+                                if (!(res & 1) || m != res_x) hard = true;  // (res_x: whose entry the lane steps over)
                             }
                         }
                         if (wr_w2) {
                             m = mrz_deep_smap_get(S, w2);
                             if (m != i) cmin = m < cmin ? m : cmin;
-                            if (m < i) cfrom = 0;
+                            if (m < i) {
+                                cfrom = 0;
+                                hard = true;
+                            }
                             m = mrz_deep_tmap_get(S, occ_t);
                             if (m != i) cmin = m < cmin ? m : cmin;
-                            if (m < i) cfrom = 0;
+                            if (m < i) {
+                                cfrom = 0;
+                                hard = true;
+                            }
                         }
-                        if (cmin < i || (f & MRZ_DF_STALE)) stop |= MRZ_DS_CONFLICT;
+                        // (what the lane plans instead must be free of earlier lanes' plans in its turn)
+                        if ((res & 1) && mrz_deep_smap_get(S, w_e) < i) hard = true;
+                        if ((res & 2) && mrz_deep_smap_get(S, fe_e) < i) hard = true;
+                        if (hard || (f & MRZ_DF_STALE)) stop |= MRZ_DS_CONFLICT;
                         // a real match (or a compare beyond the 64-byte reach) among the tag-equal entries
                         const int ns = S->R.nsame[i];
                         const int64_t floor_p = L.last_match > 0 ? L.last_match : 0;
                         for (int k = 0; k < ns; k++)
                             if (mrz_deep_pair_eval(S->R.raw[i][k], q, S->R.same_off[i][k], floor_p)) stop |= MRZ_DS_COOP;
                         // a store that takes a failing entry out of the sweep's way changes which entries later culls find
-                        if (wr_w && kind == MRZ_DK_OVER && w >= cw_base && w < cw_base + cw_len) stop |= MRZ_DS_COOP;
+                        if (wr_w && kind_e == MRZ_DK_OVER && w_e >= cw_base && w_e < cw_base + cw_len) stop |= MRZ_DS_COOP;
                         if (wr_w2 && kind2 == MRZ_DK_OVER && w2 >= cw_base && w2 < cw_base + cw_len) stop |= MRZ_DS_COOP;
                         // a slot the cooperative path has written since the scan, inside what the lane has read
                         for (int k = S->R.xw_seen[i]; k < xw_n; k++) {
                             const int xs = S->xw_slot[k];
-                            if ((((xs - h) & smask) <= ((fe - h) & smask)) || (wr_w2 && (((xs - h2) & smask) <= ((w2 - h2) & smask))))
+                            if ((((xs - h) & smask) <= ((fe_e - h) & smask)) || (wr_w2 && (((xs - h2) & smask) <= ((w2 - h2) & smask))))
                                 stop |= MRZ_DS_CULLED;
                         }
                         // culled since the scan (by earlier rounds / batches)?
                         const int64_t cp0 = S->R.cp_scan[i];
                         if (L.clean_ptr != cp0) {
                             const int lc = (int)(L.clean_ptr - cp0) + 1;
-                            if (mrz_deep_ranges_meet(h, ((fe - h) & smask) + 1, (int)cp0, lc, smask)) stop |= MRZ_DS_CULLED;
+                            if (mrz_deep_ranges_meet(h, ((fe_e - h) & smask) + 1, (int)cp0, lc, smask)) stop |= MRZ_DS_CULLED;
                             if (wr_w2 && mrz_deep_ranges_meet(h2, ((w2 - h2) & smask) + 1, (int)cp0, lc, smask)) stop |= MRZ_DS_CULLED;
                         }
                     }
@@ -1015,7 +1126,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 const bool inb = mine && i < e1;
                 const bool a_ins = inb && ins;
                 const bool a_ev = a_ins && kind == MRZ_DK_EVICT;
-                const int d = a_ins ? (kind == MRZ_DK_EMPTY ? 1 : (kind == MRZ_DK_DISPLACE ? (kind2 == MRZ_DK_EMPTY ? 1 : 0) : 0)) : 0;
+                const int d = a_ins ? (kind_e == MRZ_DK_EMPTY ? 1 : (kind == MRZ_DK_DISPLACE ? (kind2 == MRZ_DK_EMPTY ? 1 : 0) : 0)) : 0;
                 int dummy;
                 const int i1 = mrz_deep_incl(d | (a_ev ? 1 << 10 : 0) | (a_ins ? 1 << 20 : 0), S->wsum, lane, wave, &dummy);
                 int64_t c_before = L.count + ((i1 & 1023) - d);
@@ -1036,7 +1147,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     const int rr = r_before - 1 < cw_total ? r_before - 1 : cw_total - 1;
                     if (rr >= 0) {
                         const int lc = (int)(mrz_deep_cw_slot(S, cw_base, rr) - cw_base) + 1;
-                        if (mrz_deep_ranges_meet(h, ((fe - h) & smask) + 1, (int)cw_base, lc, smask) ||
+                        if (mrz_deep_ranges_meet(h, ((fe_e - h) & smask) + 1, (int)cw_base, lc, smask) ||
                             (wr_w2 && mrz_deep_ranges_meet(h2, ((w2 - h2) & smask) + 1, (int)cw_base, lc, smask)))
                             stop |= MRZ_DS_CULLED;
                     }
@@ -1053,7 +1164,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 // R6: lanes [next, e2) commit as scanned (insert_hash + clean_one_from_hash, src/rzip.c:256-328,579-584)
                 if (mine && i < e2) {
                     if (a_ins) {
-                        int ws = w;
+                        int ws = w_e;
                         if (a_ev) {
                             const int er = ((i1 >> 10) & 1023) - 1;
                             const int vr = (int)(((unsigned)L.victim_round + (unsigned)er) % (unsigned)max_chain);
