@@ -799,7 +799,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                           "batch_lanes", "cut_long", "cut_walk", "cut_conflict", "cut_cull", "batch_emits",
                                           "cut_cascade", "batch_formed", "t_walk2", "t_scans", "t_conflict", "t_window",
                                           "d_batches", "d_lanes", "d_rounds", "d_rescanned", "d_coop", "d_t_form", "d_t_scan",
-                                          "d_t_commit", "d_t_rescan", "d_t_total", "d_launches" };
+                                          "d_t_commit", "d_t_rescan", "d_t_total", "d_launches", "d_t_coop", "d_coop_rec",
+                                          "d_resolved" };
         for (int k = 0; k < 128; k++)
             if (names[k] && hs.prof[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }

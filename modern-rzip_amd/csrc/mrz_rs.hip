@@ -12,7 +12,7 @@
 //     arithmetic of the reference (:122-134) is folded into that table;
 //   * the 32 parity bytes go back through the conventional->dual table into columns 223..254 of
 //     the LDS image, and the image is written out transposed (column c of row r at
-//     c * 8176 + r, :311-321) as dwords: 4 rows per lane, 112 contiguous bytes per column.
+//     c * 8176 + r, :311-321) as 16-byte words: 16 rows per lane, 112 contiguous bytes per column.
 // The data columns are written unchanged (taltab o tal1tab = identity, :118,138).
 // Tables are generated on the host from the field polynomial, the generator roots and the 8
 // dual-basis images; nothing is copied from the reference.
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uin
         }
     }
     __syncthreads();
+#ifndef MRZ_RS_SKIP_LFSR
     if (tid < MRZ_RS_TILE) {
         // rse32: bb[j] = bb[j-1] ^ g_j * feedback, bb[0] = g_0 * feedback  (:120-135)
         uint32_t b[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -140,17 +141,30 @@ __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uin
 #pragma unroll
         for (int j = 0; j < 32; j++) par[j] = s_tal[(b[j >> 2] >> (8 * (j & 3))) & 0xff];  // :138
     }
+#endif
     __syncthreads();
-    // scatter (:311-321): dst[c * 8176 + r] = row r, column c; 4 rows per dword store
+    // scatter (:311-321): dst[c * 8176 + r] = row r, column c.  A column's 112 bytes of this tile are 7 x 16 B: a lane
+    // gathers 16 rows of one column from the image (the odd row pitch keeps the 16 byte reads of neighbouring lanes on
+    // different banks) and stores them as one 16-byte word (8176, 112 and the burst size are multiples of 16)
+#ifndef MRZ_RS_SKIP_SCATTER
     uint8_t *dst = out + burst * (int64_t)MRZ_RS_N * MRZ_RS_ROWS + (int64_t)tile * MRZ_RS_TILE;
-    const int quads = MRZ_RS_TILE / 4;  // 28
-    for (int idx = tid; idx < MRZ_RS_N * quads; idx += MRZ_RS_THREADS) {
-        const int c = idx / quads, u = idx % quads;
-        const uint8_t *p = &s_img[(4 * u) * MRZ_RS_N + c];
-        const uint32_t w = (uint32_t)p[0] | (uint32_t)p[MRZ_RS_N] << 8 | (uint32_t)p[2 * MRZ_RS_N] << 16 |
-                           (uint32_t)p[3 * MRZ_RS_N] << 24;
-        *reinterpret_cast<uint32_t *>(dst + (int64_t)c * MRZ_RS_ROWS + 4 * u) = w;
+    const int segs = MRZ_RS_TILE / 16;  // 7
+    for (int idx = tid; idx < MRZ_RS_N * segs; idx += MRZ_RS_THREADS) {
+        const int c = idx / segs, u = idx % segs;
+        const uint8_t *p = &s_img[(16 * u) * MRZ_RS_N + c];
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            w[k] = (uint32_t)p[(4 * k) * MRZ_RS_N] | (uint32_t)p[(4 * k + 1) * MRZ_RS_N] << 8 |
+                   (uint32_t)p[(4 * k + 2) * MRZ_RS_N] << 16 | (uint32_t)p[(4 * k + 3) * MRZ_RS_N] << 24;
+        uint4 v;
+        v.x = w[0];
+        v.y = w[1];
+        v.z = w[2];
+        v.w = w[3];
+        *reinterpret_cast<uint4 *>(dst + (int64_t)c * MRZ_RS_ROWS + 16 * u) = v;
     }
+#endif
 }
 
 // ---- BLAKE2b-512 on the host (the trailer hash of rs-mrzip.c:138,148 is one serial chain over

@@ -86,7 +86,8 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        MRZ_ST_CUT_CASCADE, MRZ_ST_BATCH_FORMED, MRZ_ST_T_WALK2, MRZ_ST_T_SCANS, MRZ_ST_T_CONFLICT, MRZ_ST_T_WINDOW,
        // (the deep engine's own)
        MRZ_ST_D_BATCHES, MRZ_ST_D_LANES, MRZ_ST_D_ROUNDS, MRZ_ST_D_RESCANNED, MRZ_ST_D_COOP, MRZ_ST_D_T_FORM, MRZ_ST_D_T_SCAN,
-       MRZ_ST_D_T_COMMIT, MRZ_ST_D_T_RESCAN, MRZ_ST_D_T_TOTAL, MRZ_ST_D_LAUNCHES,
+       MRZ_ST_D_T_COMMIT, MRZ_ST_D_T_RESCAN, MRZ_ST_D_T_TOTAL, MRZ_ST_D_LAUNCHES, MRZ_ST_D_T_COOP, MRZ_ST_D_COOP_REC,
+       MRZ_ST_D_RESOLVED,
        MRZ_ST_N };
 static_assert(MRZ_ST_N <= (int)(sizeof(((mrz_seq_state *)0)->prof) / sizeof(int64_t)), "mrz_seq_state.prof holds the counters");
 

@@ -1326,6 +1326,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                         const bool okc = rec ? mrz_deep_candidate_rec(C, L, S, cl, &nx_rec, lane, stat)
                                              : mrz_deep_coop(C, L, &S->coop, t, lane, stat);
                         ST_ADD(MRZ_ST_D_COOP, 1);
+                        ST_ADD(MRZ_ST_D_COOP_REC, rec ? 1 : 0);
                         const bool same_masks = L.min_mask == mm0 && L.tag_mask == tm0;
                         const int nwr = rec ? 0 : mrz_uni(S->coop.n_written);
                         const int64_t cs = rec ? -1 : mrz_uni64(S->coop.cull_slot);
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     const int nf = mrz_deep_first(i > coop_lane && i < nb && S->R.q[i] > L.p, S->wmin3, lane, wave, tid, nb);
                     next = nf;
                 }
-                PROF_ADD(MRZ_ST_D_T_RESCAN);
+                PROF_ADD(MRZ_ST_D_T_COOP);
             }
         }
         // where the next batch begins: behind the entries this one has covered -- or, when the masks have moved or a match
