@@ -5,11 +5,13 @@
 // encode() (rs-mrzip/rs-mrzip.c:119-158).  The reference encodes one row after another on one
 // core; the 8176 rows of a burst (and all bursts) are independent, so:
 //   * a 128-thread workgroup takes 112 consecutive rows (8176 = 73 x 112): their 24,976 input
-//     bytes are loaded coalesced (16 B per lane) into an LDS image with 255-byte rows;
-//   * thread t runs the 32-byte LFSR of row t: per data byte one dual->conventional look-up, one
-//     32-byte row of the precomputed "feedback x generator" table (256 x 32 B in LDS, two
-//     ds_read_b128) XORed into the shifted register held in 8 dwords -- the log/antilog
-//     arithmetic of the reference (:122-134) is folded into that table;
+//     bytes are loaded coalesced (16 B per lane) into an LDS image with 260-byte rows (4 x 65: a
+//     row's bytes can be read a dword at a time, and one column of 64 rows spans all 64 banks);
+//   * thread t runs the 32-byte LFSR of row t: per data byte one dual->conventional look-up (four
+//     at a time, ahead of the steps that use them) and one 32-byte row of the precomputed
+//     "feedback x generator" table (256 x 32 B in LDS, its halves in two arrays so that each
+//     ds_read_b128 spreads over all banks) XORed into the shifted register held in 8 dwords --
+//     the log/antilog arithmetic of the reference (:122-134) is folded into that table;
 //   * the 32 parity bytes go back through the conventional->dual table into columns 223..254 of
 //     the LDS image, and the image is written out transposed (column c of row r at
 //     c * 8176 + r, :311-321) as 16-byte words: 16 rows per lane, 112 contiguous bytes per column.
@@ -17,7 +19,8 @@
 // Tables are generated on the host from the field polynomial, the generator roots and the 8
 // dual-basis images; nothing is copied from the reference.
 //
-// Bound: HBM -- 223 B read + 255 B written per row (478 B per row).
+// Bound: 223 B read + 255 B written per row (478 B per row) against HBM; measured, the kernel is bound by the LFSR's
+// LDS traffic instead (32 B of table per data byte: without the LFSR the same kernel moves 3.1 TB/s, with it 1.3).
 #include <string.h>
 
 #include <thread>
@@ -31,6 +34,8 @@
 #define MRZ_RS_N 255
 #define MRZ_RS_TILE 112   // rows per workgroup; 8176 = 73 * 112
 #define MRZ_RS_THREADS 128
+#define MRZ_RS_PITCH 260  // bytes between the rows of the LDS image: 4 x 65 -- a row's data can be read a dword at a time, and
+                          // the dwords (and bytes) of one column of 64 consecutive rows lie on 64 different banks
 
 struct mrz_rs_tables {
     uint8_t fbgen[256][32];  // fbgen[f][j] = f * g_j in GF(256), conventional basis
@@ -79,13 +84,17 @@ static void mrz_rs_build_tables(mrz_rs_tables *T) {
 __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uint8_t *__restrict__ in, int64_t n,
                                                                        const mrz_rs_tables *__restrict__ T,
                                                                        uint8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_fb[256][32];
+    // (the two halves of a table row in arrays of their own: a 16-byte read of row f then lands on banks 4 (f % 16)..+3,
+    // all 64 banks in use -- with 32-byte rows each of the two reads had half of the banks to itself)
+    __shared__ __attribute__((aligned(16))) uint8_t s_fb_lo[256][16], s_fb_hi[256][16];
     __shared__ uint8_t s_tal[256], s_tal1[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[MRZ_RS_TILE * MRZ_RS_N + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[MRZ_RS_TILE * MRZ_RS_PITCH + 16];
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < 256 * 32 / 16; i += MRZ_RS_THREADS)
-        reinterpret_cast<uint4 *>(&s_fb[0][0])[i] = reinterpret_cast<const uint4 *>(&T->fbgen[0][0])[i];
+    for (int i = tid; i < 256 * 32 / 16; i += MRZ_RS_THREADS) {
+        const uint4 v = reinterpret_cast<const uint4 *>(&T->fbgen[0][0])[i];
+        *reinterpret_cast<uint4 *>((i & 1) ? &s_fb_hi[i >> 1][0] : &s_fb_lo[i >> 1][0]) = v;
+    }
     for (int i = tid; i < 256; i += MRZ_RS_THREADS) {
         s_tal[i] = T->tal[i];
         s_tal1[i] = T->tal1[i];
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uin
         int r = x / MRZ_RS_K, c = x % MRZ_RS_K;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            if (x + k < tile_bytes) s_img[r * MRZ_RS_N + c] = tmp[k];
+            s_img[r * MRZ_RS_PITCH + c] = tmp[k];  // (112 x 223 = 1561 x 16: no piece straddles the tile's end)
             if (++c == MRZ_RS_K) {
                 c = 0;
                 r++;
@@ -116,18 +125,20 @@ __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uin
         }
     }
     __syncthreads();
-#ifndef MRZ_RS_SKIP_LFSR
+#ifndef MRZ_RS_SKIP_LFSR  // (-DMRZ_RS_SKIP_LFSR / -DMRZ_RS_SKIP_SCATTER: ablation builds for tools/probe_rs.py, never shipped)
     if (tid < MRZ_RS_TILE) {
         // rse32: bb[j] = bb[j-1] ^ g_j * feedback, bb[0] = g_0 * feedback  (:120-135)
         uint32_t b[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        const uint8_t *row = &s_img[tid * MRZ_RS_N];
-        for (int i = MRZ_RS_K - 1; i >= 0; i--) {
-            const uint32_t fb = (uint32_t)s_tal1[row[i]] ^ (b[7] >> 24);
+        // The data bytes come a dword at a time and their dual->conventional look-ups four at a time: none of that
+        // waits for the register, so a step's critical path is the one trip to the LDS for its table row.
+        const uint32_t *row32 = reinterpret_cast<const uint32_t *>(&s_img[tid * MRZ_RS_PITCH]);
+        auto step = [&](uint32_t d) {
+            const uint32_t fb = d ^ (b[7] >> 24);
 #pragma unroll
             for (int k = 7; k > 0; k--) b[k] = (b[k] << 8) | (b[k - 1] >> 24);
             b[0] <<= 8;
-            const uint4 g0 = *reinterpret_cast<const uint4 *>(&s_fb[fb][0]);
-            const uint4 g1 = *reinterpret_cast<const uint4 *>(&s_fb[fb][16]);
+            const uint4 g0 = *reinterpret_cast<const uint4 *>(&s_fb_lo[fb][0]);
+            const uint4 g1 = *reinterpret_cast<const uint4 *>(&s_fb_hi[fb][0]);
             b[0] ^= g0.x;
             b[1] ^= g0.y;
             b[2] ^= g0.z;
@@ -136,8 +147,25 @@ __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uin
             b[5] ^= g1.y;
             b[6] ^= g1.z;
             b[7] ^= g1.w;
+        };
+        {  // bytes 222, 221, 220 (223 = 4 x 55 + 3; the top byte of this dword is the first parity column)
+            const uint32_t w = row32[MRZ_RS_K / 4];
+            const uint32_t d2 = s_tal1[(w >> 16) & 0xff], d1 = s_tal1[(w >> 8) & 0xff], d0 = s_tal1[w & 0xff];
+            step(d2);
+            step(d1);
+            step(d0);
         }
-        uint8_t *par = &s_img[tid * MRZ_RS_N + MRZ_RS_K];
+#pragma unroll 2
+        for (int j = MRZ_RS_K / 4 - 1; j >= 0; j--) {
+            const uint32_t w = row32[j];
+            const uint32_t d3 = s_tal1[w >> 24], d2 = s_tal1[(w >> 16) & 0xff], d1 = s_tal1[(w >> 8) & 0xff],
+                           d0 = s_tal1[w & 0xff];
+            step(d3);
+            step(d2);
+            step(d1);
+            step(d0);
+        }
+        uint8_t *par = &s_img[tid * MRZ_RS_PITCH + MRZ_RS_K];
 #pragma unroll
         for (int j = 0; j < 32; j++) par[j] = s_tal[(b[j >> 2] >> (8 * (j & 3))) & 0xff];  // :138
     }
@@ -151,12 +179,12 @@ __global__ __launch_bounds__(MRZ_RS_THREADS) void mrz_rs_encode_kernel(const uin
     const int segs = MRZ_RS_TILE / 16;  // 7
     for (int idx = tid; idx < MRZ_RS_N * segs; idx += MRZ_RS_THREADS) {
         const int c = idx / segs, u = idx % segs;
-        const uint8_t *p = &s_img[(16 * u) * MRZ_RS_N + c];
+        const uint8_t *p = &s_img[(16 * u) * MRZ_RS_PITCH + c];
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            w[k] = (uint32_t)p[(4 * k) * MRZ_RS_N] | (uint32_t)p[(4 * k + 1) * MRZ_RS_N] << 8 |
-                   (uint32_t)p[(4 * k + 2) * MRZ_RS_N] << 16 | (uint32_t)p[(4 * k + 3) * MRZ_RS_N] << 24;
+            w[k] = (uint32_t)p[(4 * k) * MRZ_RS_PITCH] | (uint32_t)p[(4 * k + 1) * MRZ_RS_PITCH] << 8 |
+                   (uint32_t)p[(4 * k + 2) * MRZ_RS_PITCH] << 16 | (uint32_t)p[(4 * k + 3) * MRZ_RS_PITCH] << 24;
         uint4 v;
         v.x = w[0];
         v.y = w[1];
