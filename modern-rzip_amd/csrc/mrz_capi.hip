@@ -800,7 +800,8 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
                                           "cut_cascade", "batch_formed", "t_walk2", "t_scans", "t_conflict", "t_window",
                                           "d_batches", "d_lanes", "d_rounds", "d_rescanned", "d_coop", "d_t_form", "d_t_scan",
                                           "d_t_commit", "d_t_rescan", "d_t_total", "d_launches", "d_t_coop", "d_coop_rec",
-                                          "d_resolved" };
+                                          "d_resolved", "d_s_coop", "d_s_conflict", "d_s_culled", "d_s_nocull", "d_s_stale", "d_c_over_alt", "d_c_over_noalt", "d_c_empty",
+                                          "d_c_displace", "d_c_other" };
         for (int k = 0; k < 128; k++)
             if (names[k] && hs.prof[k]) fprintf(stderr, "seqstat %-12s %lld\n", names[k], (long long)hs.prof[k]);
     }

@@ -87,7 +87,7 @@ enum { MRZ_ST_BATCHES, MRZ_ST_FORMED, MRZ_ST_COMMITTED, MRZ_ST_SEGMENTS, MRZ_ST_
        // (the deep engine's own)
        MRZ_ST_D_BATCHES, MRZ_ST_D_LANES, MRZ_ST_D_ROUNDS, MRZ_ST_D_RESCANNED, MRZ_ST_D_COOP, MRZ_ST_D_T_FORM, MRZ_ST_D_T_SCAN,
        MRZ_ST_D_T_COMMIT, MRZ_ST_D_T_RESCAN, MRZ_ST_D_T_TOTAL, MRZ_ST_D_LAUNCHES, MRZ_ST_D_T_COOP, MRZ_ST_D_COOP_REC,
-       MRZ_ST_D_RESOLVED,
+       MRZ_ST_D_RESOLVED, MRZ_ST_D_S_COOP, MRZ_ST_D_S_CONFLICT, MRZ_ST_D_S_CULLED, MRZ_ST_D_S_NOCULL, MRZ_ST_D_S_STALE, MRZ_ST_D_C_OVER_ALT, MRZ_ST_D_C_OVER_NOALT, MRZ_ST_D_C_EMPTY, MRZ_ST_D_C_DISPLACE, MRZ_ST_D_C_OTHER,
        MRZ_ST_N };
 static_assert(MRZ_ST_N <= (int)(sizeof(((mrz_seq_state *)0)->prof) / sizeof(int64_t)), "mrz_seq_state.prof holds the counters");
 

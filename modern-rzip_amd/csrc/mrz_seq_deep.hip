@@ -1222,6 +1222,19 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                 PROF_ADD(MRZ_ST_D_T_COMMIT);
                 if (next < nb) {
                     const int sf = mrz_uni(S->ctl[4]);
+                    ST_ADD(MRZ_ST_D_S_COOP, (sf & MRZ_DS_COOP) ? 1 : 0);
+                    ST_ADD(MRZ_ST_D_S_CONFLICT, (sf & MRZ_DS_CONFLICT) ? 1 : 0);
+                    ST_ADD(MRZ_ST_D_S_CULLED, (sf & MRZ_DS_CULLED) ? 1 : 0);
+                    ST_ADD(MRZ_ST_D_S_NOCULL, (sf & MRZ_DS_NOCULL) ? 1 : 0);
+                    ST_ADD(MRZ_ST_D_S_STALE, (S->R.flags[next] & MRZ_DF_STALE) ? 1 : 0);
+                    if ((sf & MRZ_DS_CONFLICT) && !(sf & MRZ_DS_COOP)) {  // what kind of plan the conflicting lane had
+                        const int kk = S->R.kind[next];
+                        ST_ADD(MRZ_ST_D_C_OVER_ALT, (kk == MRZ_DK_OVER && S->R.alt_w[next] >= 0) ? 1 : 0);
+                        ST_ADD(MRZ_ST_D_C_OVER_NOALT, (kk == MRZ_DK_OVER && S->R.alt_w[next] < 0) ? 1 : 0);
+                        ST_ADD(MRZ_ST_D_C_EMPTY, kk == MRZ_DK_EMPTY ? 1 : 0);
+                        ST_ADD(MRZ_ST_D_C_DISPLACE, kk == MRZ_DK_DISPLACE ? 1 : 0);
+                        ST_ADD(MRZ_ST_D_C_OTHER, (kk == MRZ_DK_NONE || kk == MRZ_DK_EVICT) ? 1 : 0);
+                    }
                     // (a lane that stops the round for the cooperative path AND whose scan no longer holds is scanned again
                     // first: its record then serves the replay)
                     bool stop_stale = (sf & (MRZ_DS_CONFLICT | MRZ_DS_CULLED)) != 0 || (S->R.flags[next] & MRZ_DF_STALE);
