@@ -86,11 +86,13 @@ def test_sequencer_workgroups_take_turns(emu_lib, oracle, wgs, monkeypatch):
 
 
 def _deep_mix():
-    """Level-1 input (2 MiB table) that takes the deep engine through its states: noise until the table is full and the
-    culling has begun (before that no lane is scanned), then text (tag-equal entries, real matches: record replay and
-    cooperative path between bulk commits), a repeat of earlier noise (one long match, lanes dropped behind it) and
-    noise again."""
-    noise = _util.xorshift_noise(1700000, seed=3)
+    """Level-1 input (2 MiB table) that takes the deep engine through its states: noise until the table is nearly full
+    (no lane is scanned before the first cull: 2.6 MB leave hash_count at 83.7 k of the 87.4 k limit -- the 1.7 MB this
+    test used until round 3 never got there, and the bulk rounds never ran in it), then text, during which the culling
+    begins (tag-equal entries, real matches: record replay and cooperative path between bulk commits, culls in every
+    round, lanes of one run settled inside a round), a repeat of earlier noise (one long match, lanes dropped behind
+    it) and noise again; the sweep has wrapped once by the end (min_mask 31)."""
+    noise = _util.xorshift_noise(2600000, seed=3)
     return noise + _util.zipf_text(420000, seed=4) + noise[300000:420000] + _util.xorshift_noise(150000, seed=8)
 
 
@@ -101,6 +103,7 @@ def test_deep_engine_alone(emu_lib, oracle, monkeypatch):
     monkeypatch.setenv("MRZ_SEQ_ENGINE", "deep")
     want = _parity.check_chunk(emu_lib, oracle, _deep_mix(), level=1, table=True, victim_round=1)
     assert want["stats"]["inserts"] > want["hash_count"] and want["stats"]["matches"] >= 2 and want["stats"]["tag_hits"] > 10
+    assert want["min_mask"] == 31  # the cull sweep has been through the table: the scanned (bulk) rounds have run
     _parity.check_chunk(emu_lib, oracle, _util.rep64k(40, seed=9, period=997), level=2, table=True)
     blk = _util.xorshift_noise(70000, seed=12)
     _parity.check_chunk(emu_lib, oracle, blk + blk + b"xyz" + blk[5:])
