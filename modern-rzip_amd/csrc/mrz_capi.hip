@@ -149,6 +149,10 @@ extern "C" int mrz_open(mrz_ctx **out, int device, int level, int64_t max_chunk)
         if (e && !strcmp(e, "deep")) ctx->engine_pin = 3;
         ctx->deep_min_bits = 6;
         if (const char *d = getenv("MRZ_DEEP_MIN_BITS")) ctx->deep_min_bits = atoi(d);
+        // (at deep masks the narrow engine's one-wave table walks cost 70 us per candidate: stride-64G 20.2 s with it,
+        // 8.1 s when those segments go to the deep engine too; rep64k-10G, whose mask stays below, is unchanged)
+        ctx->narrow_max_bits = ctx->deep_min_bits;
+        if (const char *d = getenv("MRZ_NARROW_MAX_BITS")) ctx->narrow_max_bits = atoi(d);
         e = getenv("MRZ_PRINT_PROF");
         if (e) ctx->print_prof = !strcmp(e, "narrow") ? 2 : 1;
     }
@@ -660,11 +664,12 @@ extern "C" int mrz_rzip_chunk(mrz_ctx *ctx, const void *chunk, int64_t n, int wh
         // narrow engine's shorter chain per match wins.  The hint lags behind like everything the host knows; the first
         // two launches are waited for so that it arrives early.  MRZ_SEQ_ENGINE=wide|narrow pins the choice (tests,
         // measurements).
-        bool narrow = hint_pos > 0 && hint_matched * 10 >= hint_pos * 8;
+        const int mask_bits = __builtin_popcountll((unsigned long long)known_mask);
+        bool narrow = hint_pos > 0 && hint_matched * 10 >= hint_pos * 8 && mask_bits < ctx->narrow_max_bits;
         // ... and the deep engine once the cull sweeps have tightened the mask: the table then consists of a few long
         // runs (2^(hash_bits - k) of about 2/3 x 2^k slots under a k-bit mask) that every look-up reads to the end --
         // streaming scans, not the short walks the wide engine's lanes are made for
-        bool deep = !narrow && __builtin_popcountll((unsigned long long)known_mask) >= ctx->deep_min_bits;
+        bool deep = !narrow && mask_bits >= ctx->deep_min_bits;
         if (ctx->engine_pin) narrow = ctx->engine_pin == 2, deep = ctx->engine_pin == 3;
         const int helpers = ctx->farm_helpers >= 0 && ctx->farm_helpers < ctx->farm_default ? ctx->farm_helpers : ctx->farm_default;
         PROF_BEGIN(1);

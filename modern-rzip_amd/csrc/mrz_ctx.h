@@ -40,6 +40,7 @@ struct mrz_ctx {
     int64_t cand_cap;      // entries a pass may fill (MRZ_CAND_CAP unless a test shrinks it)
     int engine_pin;        // MRZ_SEQ_ENGINE at mrz_open: 0 per-segment choice, 1 wide, 2 narrow, 3 deep
     int deep_min_bits;     // bits of minimum_tag_mask from which a segment runs on the deep engine (MRZ_DEEP_MIN_BITS)
+    int narrow_max_bits;   // ... and from which a run of long matches no longer goes to the narrow engine (MRZ_NARROW_MAX_BITS)
     int print_prof;        // MRZ_PRINT_PROF at mrz_open
     int xcd;               // block index mod 8 of this ctx's sequencer workgroups (concurrent ctxs: one XCD each)
     mrz_event *d_events;

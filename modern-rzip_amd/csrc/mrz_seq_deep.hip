@@ -1229,6 +1229,7 @@ __global__ __launch_bounds__(MRZ_DEEP_THREADS) void mrz_seq_deep_kernel(mrz_seq_
                     ST_ADD(MRZ_ST_D_S_STALE, (S->R.flags[next] & MRZ_DF_STALE) ? 1 : 0);
                     if ((sf & MRZ_DS_CONFLICT) && !(sf & MRZ_DS_COOP)) {  // what kind of plan the conflicting lane had
                         const int kk = S->R.kind[next];
+                        (void)kk;
                         ST_ADD(MRZ_ST_D_C_OVER_ALT, (kk == MRZ_DK_OVER && S->R.alt_w[next] >= 0) ? 1 : 0);
                         ST_ADD(MRZ_ST_D_C_OVER_NOALT, (kk == MRZ_DK_OVER && S->R.alt_w[next] < 0) ? 1 : 0);
                         ST_ADD(MRZ_ST_D_C_EMPTY, kk == MRZ_DK_EMPTY ? 1 : 0);

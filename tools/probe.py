@@ -42,6 +42,7 @@ if "noise2g" in which: run("noise-2GiB", w.noise_device(2 << 30, "cuda"))
 if "noise8g" in which: run("noise-8GiB", w.noise_device(8 << 30, "cuda"))
 if "noise32g" in which: run("noise-32GiB", w.noise_device(32 << 30, "cuda"))
 if "tar64g" in which: run("tar-64GiB", w.tar_like_device(64 << 30, "cuda"))
+if "stride64g" in which: run("stride-64GiB", w.stride_stream_device(16, 4 << 30, "cuda"))
 if "tar8g" in which: run("tar-8GiB", w.tar_like_device(8 << 30, "cuda"))
 if "rep64" in which: run("rep64k-64MiB", w.rep64k_device(1024, "cuda"))
 if "rep1g" in which: run("rep64k-1GiB", w.rep64k_device(16384, "cuda"))
